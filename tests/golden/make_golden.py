@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the REFERENCE itself.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    HELION_CACHE_DIR=/tmp/helicon_golden_cache PYTHONDONTWRITEBYTECODE=1 \
+        PYTHONPATH=/root/reference/src python3 tests/golden/make_golden.py
+
+Every array written is an INPUT or an OUTPUT of a reference function; no reference source
+text is stored.  Stage 2 (``compute_power_spectra``) cannot run here (finufft is not
+installed), so the composed fixtures G3 use the reference's own post-processing functions
+(``normalize_percentile``, ``cross_correlation_coefficient``) around ``np.fft.fft2``, which is
+what ``fft_rescale`` evaluates for default arguments (reference transforms.py:696-711).
+"""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+import helicon  # the reference
+from helicon.lib import analysis, filters, angular
+from helicon.webApps.denovo3D import utils
+
+OUT = Path(__file__).resolve().parent
+
+
+def versions():
+    import scipy
+
+    return dict(helicon=helicon.__version__, numpy=np.__version__, scipy=scipy.__version__,
+                python=sys.version.split()[0])
+
+
+def g1_simulate():
+    """B1 outputs, deterministic branch (n=1, polymer=0) + seeded n>1 branch."""
+    cases = [
+        # (n, twist, rise, csym, diameter, ball_radius, ny, nx, apix, tilt, rot, psi, dy)
+        (1, 29.0, 10.0, 1, 25.6, 4.0, 32, 32, 2.0, 0, 0, 0, 0),
+        (1, 30.0, 5.0, 1, 40.0, 3.0, 32, 32, 2.0, 0, 0, 0, 0),
+        (1, 30.0, 5.0, 1, 40.0, 3.0, 32, 32, 2.0, 5, 0, 10, 2),
+        (1, -27.5, 7.25, 3, 60.0, 5.0, 64, 64, 2.0, 0, 30.0, 0, 0),
+        (1, 1.2, 4.75, 1, 25.6, 2.0, 64, 64, 1.0, 0, 0, 0, 0),
+        (1, 65.3, 23.1, 2, 100.0, 10.0, 64, 64, 5.0, 3.0, 15.0, -4.0, -6.0),
+        (1, 12.0, 8.0, 1, 60.0, 6.0, 48, 96, 2.0, 0, 0, 0, 0),
+        (1, -12.0, 8.0, 4, 60.0, 6.0, 48, 96, 2.0, 0, 45.0, 0, 3.5),
+        (1, 179.1, 2.4, 1, 30.0, 2.5, 32, 32, 2.0, 0, 0, 0, 0),
+        (1, 29.0, 10.0, 6, 50.0, 4.0, 64, 64, 2.0, 0, 0, 0, 0),
+    ]
+    arrs = {}
+    for k, c in enumerate(cases):
+        n, tw, rs, cs, d, br, ny, nx, apix, tilt, rot, psi, dy = c
+        out = utils.simulate_helical_projection(n, tw, rs, cs, d, br, 0, 0, ny, nx, apix,
+                                                tilt=tilt, rot=rot, psi=psi, dy=dy)
+        arrs[f"case{k}_args"] = np.asarray(c, dtype=np.float64)
+        arrs[f"case{k}_out"] = out
+    # seeded multi-unit branch (reference tests/test_denovo3D_utils.py:107-143 inputs)
+    for k, kw in enumerate([dict(), dict(tilt=5, psi=10, dy=2)]):
+        np.random.seed(1234 + k)
+        out = utils.simulate_helical_projection(10, 30, 5, 1, 40, 3, 0, 0, 32, 32, 2.0, **kw)
+        arrs[f"multi{k}_seed"] = np.asarray([1234 + k])
+        arrs[f"multi{k}_kw"] = np.asarray([kw.get("tilt", 0), kw.get("psi", 0), kw.get("dy", 0)], dtype=np.float64)
+        arrs[f"multi{k}_out"] = out
+    arrs["n_cases"] = np.asarray([len(cases)])
+    np.savez_compressed(OUT / "g1_simulate.npz", **arrs)
+
+
+def g2_scores():
+    """B3 / A7 on seeded vectors, incl. zero-variance -> 0."""
+    arrs = {}
+    for n in (3, 1000, 65536):
+        rng = np.random.default_rng(n)
+        a = rng.normal(size=n)
+        b = 0.3 * a + rng.normal(size=n)
+        a32, b32 = a.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+        if n <= 1000:  # larger inputs are regenerated from the seed (= n) by the test
+            arrs[f"n{n}_a"] = a.astype(np.float32)
+            arrs[f"n{n}_b"] = b.astype(np.float32)
+        arrs[f"n{n}_cc"] = np.asarray([analysis.cross_correlation_coefficient(a32, b32)])
+        arrs[f"n{n}_cos"] = np.asarray([analysis.cosine_similarity(a32, b32)])
+    const = np.full(17, 2.5)
+    ramp = np.arange(17, dtype=np.float64)
+    arrs["const_cc"] = np.asarray([float(analysis.cross_correlation_coefficient(ramp, const))])
+    arrs["zero_cos"] = np.asarray([float(analysis.cosine_similarity(ramp, const * 0))])
+    np.savez_compressed(OUT / "g2_scores.npz", **arrs)
+
+
+def _pwr(img, log):
+    fft = np.fft.fftshift(np.fft.fft2(img.astype(np.complex128)))
+    pwr = np.log1p(np.abs(fft)) if log else np.abs(fft)
+    return filters.normalize_percentile(pwr, percentile=(0, 100))
+
+
+def _band(n, r_lo, r_hi):
+    k = np.arange(n) - n // 2
+    r2 = k[:, None].astype(np.float64) ** 2 + k[None, :].astype(np.float64) ** 2
+    return (r2 > r_lo**2) & (r2 < r_hi**2)
+
+
+def g3_composed():
+    """Composed Path-B scores on a noisy synthetic helix: 9 x 5 grid, log in {True, False}."""
+    arrs = {}
+    for n, apix, truth, twists, rises in (
+        (64, 2.0, (29.0, 10.0, 1), np.arange(25.0, 33.0 + 0.5, 1.0), np.arange(8.0, 12.0 + 0.5, 1.0)),
+        (128, 2.0, (29.0, 10.0, 1), np.arange(25.0, 33.0 + 0.5, 1.0), np.arange(8.0, 12.0 + 0.5, 1.0)),
+        (64, 2.0, (-40.0, 7.0, 3), np.arange(-44.0, -36.0 + 0.5, 1.0), np.arange(5.0, 9.0 + 0.5, 1.0)),
+    ):
+        tw0, rs0, cs0 = truth
+        d = 0.4 * n * apix
+        br = 2 * apix
+        clean = utils.simulate_helical_projection(1, tw0, rs0, cs0, d, br, 0, 0, n, n, apix)
+        noise = np.random.default_rng(0).normal(0, 0.5 * clean.std(), clean.shape)
+        img = (clean + noise).astype(np.float32)
+        mask = _band(n, 2, n // 2 - 1)
+        tag = f"n{n}_c{cs0}"
+        arrs[f"{tag}_image"] = img
+        arrs[f"{tag}_meta"] = np.asarray([n, apix, tw0, rs0, cs0, d, br], dtype=np.float64)
+        arrs[f"{tag}_twists"] = twists
+        arrs[f"{tag}_rises"] = rises
+        for log in (True, False):
+            pe = _pwr(img.astype(np.float64), log)
+            sc = np.zeros((len(twists), len(rises)))
+            for i, tw in enumerate(twists):
+                for j, rs in enumerate(rises):
+                    sim = utils.simulate_helical_projection(1, float(tw), float(rs), cs0, d, br, 0, 0, n, n, apix)
+                    ps = _pwr(sim, log)
+                    sc[i, j] = analysis.cross_correlation_coefficient(pe[mask], ps[mask])
+            arrs[f"{tag}_scores_log{int(log)}"] = sc
+            arrs[f"{tag}_argmax_log{int(log)}"] = np.asarray(np.unravel_index(np.argmax(sc), sc.shape))
+    np.savez_compressed(OUT / "g3_composed.npz", **arrs)
+
+
+def g6_filters():
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=(32, 32))
+    arrs = dict(x=x)
+    arrs["lp"] = filters.low_high_pass_filter(x, low_pass_fraction=0.3)
+    arrs["hp"] = filters.low_high_pass_filter(x, high_pass_fraction=0.1)
+    arrs["lphp"] = filters.low_high_pass_filter(x, low_pass_fraction=0.5, high_pass_fraction=0.05)
+    arrs["norm_0_100"] = filters.normalize_percentile(x, (0, 100))
+    arrs["norm_10_90"] = filters.normalize_percentile(x, (10, 90))
+    arrs["periodic_in"] = np.asarray([-540.0, -181.0, -180.0, -0.5, 0.0, 179.99, 180.0, 180.5, 359.0, 725.0])
+    arrs["periodic_out"] = np.asarray([angular.set_to_periodic_range(float(v), -180, 180) for v in arrs["periodic_in"]])
+    np.savez_compressed(OUT / "g6_filters.npz", **arrs)
+
+
+if __name__ == "__main__":
+    assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
+    g1_simulate()
+    g2_scores()
+    g3_composed()
+    g6_filters()
+    (OUT / "VERSIONS.json").write_text(json.dumps(versions(), indent=1) + "\n")
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size)
