@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: helical-parameter candidates/s on a 512x512 image over a 100k-point
+(twist, rise) grid (BASELINE.json configs[1] = SURVEY.md section 8d "C2"), one MI355X per rank.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the sweep over this rank's 100k-candidate shard with the parameters and the
+experimental spectrum already resident in HBM, followed (N > 1) by the RCCL all-gather of the
+scores.  Weak scaling: every rank owns one full 400 x 250 grid (rank r sweeps it with
+Csym = 1 + r % 6, the C3 workload at N = 6), so the job is 100k x N candidates per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md "HBM3E peak BW")
+
+
+def c2_workload(n=512):
+    from helicon_amd.grid import build_grid, sweep_axis
+
+    apix = 1.0
+    twists = sweep_axis(0.01, 4.00, 0.01)
+    rises = sweep_axis(4.000, 5.245, 0.005)
+    return dict(n=n, apix=apix, truth=(1.20, 4.75, 1), helical_diameter=0.4 * n * apix, ball_radius=2 * apix,
+                twists=twists, rises=rises, build_grid=build_grid)
+
+
+def cpu_baseline_leg(w, sample_per_core=24):
+    """The CPU oracle (NumPy port of the reference path) on this host's cores, bounded sample."""
+    from oracle import cpu_baseline
+
+    cores = len(os.sched_getaffinity(0))
+    return cpu_baseline.run(n=w["n"], apix=w["apix"], helical_diameter=w["helical_diameter"],
+                            ball_radius=w["ball_radius"], truth=w["truth"], twists=w["twists"], rises=w["rises"],
+                            cores=cores, n_candidates=sample_per_core * cores)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=512, help="image side (default: the C2 workload)")
+    ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    w = c2_workload(args.n)
+
+    # CPU baseline first, before this process touches the GPU (it uses worker processes)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(w)
+
+    import torch
+    import torch.distributed as dist
+
+    import helicon_amd as H
+    from helicon_amd.distributed import gather_scores
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = w["n"]
+    eng = H.SweepEngine(n, device=local_rank, max_batch=args.max_batch)
+    eng.set_geometry(apix=w["apix"], helical_diameter=w["helical_diameter"], ball_radius=w["ball_radius"])
+    tw0, rs0, cs0 = w["truth"]
+    clean = eng.simulate(tw0, rs0, cs0)
+    noise = np.random.default_rng(0).normal(0, 0.5 * clean.std(), clean.shape)
+    image = (clean + noise).astype(np.float32)
+    eng.set_reference(image, H.radial_band_mask(n, n), log=True)
+
+    csym = 1 + rank % 6
+    grid = w["build_grid"](w["twists"], w["rises"], (csym,), tube_length=n * w["apix"])
+    assert grid.valid.all()
+    g_local = len(grid)
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)
+    d_params = torch.from_numpy(grid.params).to(dev)
+    d_scores = torch.empty((1, g_local), dtype=torch.float32, device=dev)
+
+    def step():
+        eng.sweep_device(d_params.data_ptr(), g_local, d_scores.data_ptr())
+        if world > 1:
+            return gather_scores(d_scores, g_local * world, g_local)
+        return d_scores
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_get() if not args.no_profile else None
+    eng.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed: arg-max of this rank's own grid; rank 0 (csym 1) must find the truth
+    scores = full.cpu().numpy().reshape(world, g_local)
+    best = int(np.argmax(scores[0]))
+    _, bt, br_ = np.unravel_index(best, (1, len(w["twists"]), len(w["rises"])))
+    best_pair = (round(float(grid.params[best, 0]), 6), round(float(grid.params[best, 1]), 6))
+
+    if rank == 0:
+        total = g_local * world * args.steps
+        value = total / elapsed
+        b_alg = eng.algorithmic_bytes()
+        out = {
+            "metric": "helical-param candidates/sec (512x512 image, 100k-pt grid)",
+            "value": value,
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), "
+                            f"400x250 (twist, rise) grid per GPU, Csym = 1 + rank % 6, radial-band mask, log1p|F|",
+                "image": n, "grid_per_gpu": g_local, "candidates_per_step": g_local * world,
+                "batch": eng.max_batch, "parallelism": f"grid-shard x{world} + all-gather(scores)",
+            },
+            "argmax": {"twist": best_pair[0], "rise": best_pair[1], "is_truth": best_pair == (tw0, rs0)},
+            "hbm_roofline_frac_wall": value / world * b_alg / HBM_PEAK,
+        }
+        if prof is not None and prof["n_second_pass"] > 0:
+            out["roofline"] = roofline(prof, n, b_alg)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(prof, n, b_alg):
+    """Dominant kernel against the HBM roofline.  Algorithmic bytes per candidate:
+    first pass  = 4 N^2 (the real image it stands for) + 8 N (N/2+1) written,
+    second pass = 8 N (N/2+1) read;  their sum is B_alg(N) of BASELINE.md section 3."""
+    half = 8 * n * (n // 2 + 1)
+    per = {"first_pass": (prof["ms_first_pass"], prof["n_first_pass"], 4 * n * n + half),
+           "second_pass": (prof["ms_second_pass"], prof["n_second_pass"], half)}
+    cand = prof["candidates"]
+    kernels = {}
+    for name, (ms, launches, bytes_per_cand) in per.items():
+        per_launch = cand / launches
+        avg_us = 1e3 * ms / launches
+        kernels[name] = {"launches": launches, "avg_us": avg_us, "candidates_per_launch": per_launch,
+                         "alg_bytes_per_candidate": bytes_per_cand,
+                         "GBps": bytes_per_cand * per_launch / (avg_us * 1e-6) / 1e9}
+    dom = max(kernels, key=lambda k: per[k][0])
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"  # written from the rocprofv3 --pmc passes
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get(f"n{n}", {}).get(dom)
+        except Exception:
+            traffic = None
+    achieved = kernels[dom]["GBps"]
+    pipeline_ms = prof["ms_first_pass"] + prof["ms_second_pass"] + prof["ms_finalize"]
+    return {
+        "bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+        "kernels": kernels,
+        "pipeline": {"alg_bytes_per_candidate": b_alg, "device_ms": pipeline_ms,
+                     "GBps": b_alg * cand / (pipeline_ms * 1e-3) / 1e9,
+                     "frac": b_alg * cand / (pipeline_ms * 1e-3) / HBM_PEAK},
+    }
+
+
+if __name__ == "__main__":
+    main()

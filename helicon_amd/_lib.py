@@ -1,0 +1,119 @@
+"""ctypes binding of libhelicon_hip.so (include/helicon_hip.h).
+
+There is deliberately no CPU fallback: if the shared library is missing, or no gfx950 device
+is visible, every entry point raises ``HeliconHipError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+__all__ = ["HeliconHipError", "lib", "lib_path", "hh_geom", "hh_profile", "check", "EXPORTS"]
+
+_HERE = Path(__file__).resolve().parent
+
+
+class HeliconHipError(RuntimeError):
+    """A libhelicon_hip call failed (message from ``hh_last_error``)."""
+
+
+class hh_geom(C.Structure):
+    _fields_ = [
+        ("apix", C.c_double),
+        ("helical_diameter", C.c_double),
+        ("ball_radius", C.c_double),
+        ("tilt", C.c_double),
+        ("psi", C.c_double),
+        ("dy", C.c_double),
+        ("n_units", C.c_int32),
+        ("tail_bits", C.c_int32),
+        ("units", C.POINTER(C.c_float)),
+    ]
+
+
+class hh_profile(C.Structure):
+    _fields_ = [
+        ("ms_first_pass", C.c_double),
+        ("ms_second_pass", C.c_double),
+        ("ms_finalize", C.c_double),
+        ("n_first_pass", C.c_int64),
+        ("n_second_pass", C.c_int64),
+        ("n_finalize", C.c_int64),
+        ("candidates", C.c_int64),
+    ]
+
+
+_ctx = C.c_void_p
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); exactly the symbols include/helicon_hip.h declares
+EXPORTS = {
+    "hh_abi_version": (C.c_int, []),
+    "hh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "hh_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int]),
+    "hh_destroy": (None, [_ctx]),
+    "hh_max_batch": (C.c_int, [_ctx]),
+    "hh_last_error": (C.c_char_p, [_ctx]),
+    "hh_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "hh_set_geometry": (C.c_int, [_ctx, C.POINTER(hh_geom)]),
+    "hh_set_reference": (C.c_int, [_ctx, _f32p, C.c_int, C.POINTER(C.c_uint8), C.c_int]),
+    "hh_sweep": (C.c_int, [_ctx, _f64p, C.c_int64, _f32p]),
+    "hh_sweep_device": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hh_argmax": (C.c_int, [_f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    "hh_simulate": (C.c_int, [_ctx, _f64p, _f32p]),
+    "hh_power_spectrum": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),
+    "hh_cross_correlation": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f64p]),
+    "hh_cosine_similarity": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f64p]),
+    "hh_cross_correlation_f64": (C.c_int, [_ctx, _f64p, _f64p, C.c_int64, _f64p]),
+    "hh_cosine_similarity_f64": (C.c_int, [_ctx, _f64p, _f64p, C.c_int64, _f64p]),
+    "hh_synchronize": (C.c_int, [_ctx]),
+    "hh_profile_enable": (C.c_int, [_ctx, C.c_int]),
+    "hh_profile_reset": (C.c_int, [_ctx]),
+    "hh_profile_get": (C.c_int, [_ctx, C.POINTER(hh_profile)]),
+    "hh_algorithmic_bytes": (C.c_int64, [C.c_int]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    env = os.environ.get("HELICON_HIP_LIB")
+    return Path(env) if env else _HERE / "libhelicon_hip.so"
+
+
+def lib():
+    """Load (once) and return the shared library with prototypes attached."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise HeliconHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); helicon_amd has no CPU fallback"
+        )
+    try:
+        handle = C.CDLL(str(path))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise HeliconHipError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in EXPORTS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HeliconHipError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.hh_abi_version() != 1:
+        raise HeliconHipError(f"{path}: ABI version {handle.hh_abi_version()} != 1")
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc == 0:
+        return
+    msg = lib().hh_last_error(ctx)
+    kind = {-1: ValueError, -3: HeliconHipError}.get(rc, HeliconHipError)
+    raise kind(f"libhelicon_hip error {rc}: {msg.decode() if msg else '?'}")

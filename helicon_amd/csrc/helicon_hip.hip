@@ -1,0 +1,1282 @@
+// helicon_hip.hip — MI355X (gfx950 / CDNA4) kernels + C ABI for the denovo3D (twist, rise, Csym)
+// sweep.  See include/helicon_hip.h for the boundary and DESIGN.md for the data layout.
+//
+// Per candidate (reference semantics in brackets):
+//   K_A  k_first_pass   rasterise the helical lattice of Gaussian balls straight into LDS
+//                       [utils.py:91-106, 153-172], FFT every image COLUMN (along y) with two real
+//                       columns packed into one complex transform, write the half spectrum
+//                       H[ky in 0..N/2-1][x] (row 0 packs ky=0 and ky=N/2) to HBM.
+//   K_B  k_second_pass  FFT every row of H along x -> F[ky][kx] on the half plane, then
+//                       a=|F|, q=log1p(a) [transforms.py:805-810] and the three masked moments
+//                       sum w q, sum w q^2, sum w (E-Ebar) q with Hermitian weights w in {0,1,2},
+//                       wave-shuffle + LDS reduced.
+//   K_C  k_finalize     Pearson coefficient from the moments [analysis.py:793-799].
+// Everything is wave64 code: an N-point FFT is owned by N/8 lanes holding 8 points each
+// (one wavefront for N = 512), Stockham radix-8/4/2 stages exchange through LDS.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/helicon_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// small complex helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// LDS index padding: one extra complex slot every 8 breaks the power-of-two strides of the
+// Stockham scatter (stride 8 / 64 complex) across the 32/64 LDS banks.
+__host__ __device__ constexpr int lds_pad(int a) { return a + (a >> 3); }
+
+template <int R>
+__device__ __forceinline__ void bfly(float2 (&a)[R]);
+
+template <>
+__device__ __forceinline__ void bfly<2>(float2 (&a)[2]) {
+  float2 t = a[0];
+  a[0] = cadd(t, a[1]);
+  a[1] = csub(t, a[1]);
+}
+
+template <>
+__device__ __forceinline__ void bfly<4>(float2 (&a)[4]) {
+  float2 s0 = cadd(a[0], a[2]), d0 = csub(a[0], a[2]);
+  float2 s1 = cadd(a[1], a[3]), d1 = mul_mi(csub(a[1], a[3]));
+  a[0] = cadd(s0, s1);
+  a[2] = csub(s0, s1);
+  a[1] = cadd(d0, d1);
+  a[3] = csub(d0, d1);
+}
+
+template <>
+__device__ __forceinline__ void bfly<8>(float2 (&a)[8]) {
+  constexpr float h = 0.70710678118654752440f;
+  float2 e[4] = {cadd(a[0], a[4]), cadd(a[1], a[5]), cadd(a[2], a[6]), cadd(a[3], a[7])};
+  float2 o0 = csub(a[0], a[4]), t1 = csub(a[1], a[5]), t2 = csub(a[2], a[6]), t3 = csub(a[3], a[7]);
+  float2 o[4] = {o0, make_float2((t1.x + t1.y) * h, (t1.y - t1.x) * h), mul_mi(t2),
+                 make_float2((t3.y - t3.x) * h, -(t3.x + t3.y) * h)};
+  bfly<4>(e);
+  bfly<4>(o);
+  a[0] = e[0]; a[1] = o[0]; a[2] = e[1]; a[3] = o[1];
+  a[4] = e[2]; a[5] = o[2]; a[6] = e[3]; a[7] = o[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// FFT plan: radices per N (product = N), 8 points per lane, T = N/8 lanes per transform
+// ------------------------------------------------------------------------------------------
+template <int N> struct Plan;
+template <> struct Plan<32>   { static constexpr int n = 2; static constexpr int r0 = 8, r1 = 4, r2 = 1, r3 = 1; };
+template <> struct Plan<64>   { static constexpr int n = 2; static constexpr int r0 = 8, r1 = 8, r2 = 1, r3 = 1; };
+template <> struct Plan<128>  { static constexpr int n = 3; static constexpr int r0 = 8, r1 = 8, r2 = 2, r3 = 1; };
+template <> struct Plan<256>  { static constexpr int n = 3; static constexpr int r0 = 8, r1 = 8, r2 = 4, r3 = 1; };
+template <> struct Plan<512>  { static constexpr int n = 3; static constexpr int r0 = 8, r1 = 8, r2 = 8, r3 = 1; };
+template <> struct Plan<1024> { static constexpr int n = 4; static constexpr int r0 = 8, r1 = 8, r2 = 8, r3 = 2; };
+
+constexpr int tw_count(int r) { return r > 1 ? 8 - 8 / r : 0; }  // twiddles a lane needs in a radix-r stage
+template <int N> struct TwN {
+  using P = Plan<N>;
+  static constexpr int off1 = 0;
+  static constexpr int off2 = off1 + tw_count(P::r1);
+  static constexpr int off3 = off2 + tw_count(P::r2);
+  static constexpr int total = off3 + tw_count(P::r3) + 1;  // +1: never a zero-length array
+};
+
+// Twiddles depend on the lane only, so a lane fetches them once (from a float64-rounded table
+// W_N[k] = exp(-2 pi i k / N)) and keeps them in registers across all its transforms.
+template <int N, int R, int NS, int OFF>
+__device__ __forceinline__ void load_stage_twiddles(float2* tw, int t, const float2* __restrict__ table) {
+  constexpr int T = N / 8, NB = 8 / R;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int j = t + q * T;
+    const int k = j & (NS - 1);
+#pragma unroll
+    for (int r = 1; r < R; ++r) tw[OFF + q * (R - 1) + (r - 1)] = table[(r * k * (N / (NS * R))) & (N - 1)];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void load_twiddles(float2 (&tw)[TwN<N>::total], int t, const float2* __restrict__ table) {
+  using P = Plan<N>;
+  load_stage_twiddles<N, P::r1, P::r0, TwN<N>::off1>(tw, t, table);
+  if constexpr (P::n > 2) load_stage_twiddles<N, P::r2, P::r0 * P::r1, TwN<N>::off2>(tw, t, table);
+  if constexpr (P::n > 3) load_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::off3>(tw, t, table);
+}
+
+// One Stockham stage.  Lane t owns butterflies j = t + q*T (q < 8/R); butterfly j reads
+// in[j + r*N/R] — always the lane's own register slots v[q + r*(8/R)] — and writes
+// out[(j/NS)*NS*R + (j mod NS) + r*NS].  The last stage's outputs land back in the same slots,
+// so on return v[m] = X[t + m*T].
+template <int N, int R, int NS, bool LAST, int OFF>
+__device__ __forceinline__ void fft_stage(float2 (&v)[8], const float2* tw, int t, float2* buf) {
+  constexpr int T = N / 8, NB = 8 / R;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    float2 a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = v[q + r * NB];
+    if constexpr (NS > 1) {
+#pragma unroll
+      for (int r = 1; r < R; ++r) a[r] = cmul(a[r], tw[OFF + q * (R - 1) + (r - 1)]);
+    }
+    bfly<R>(a);
+    if constexpr (LAST) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[q + r * NB] = a[r];
+    } else {
+      const int j = t + q * T;
+      const int k = j & (NS - 1);
+      const int j0 = (j - k) * R + k;
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[lds_pad(j0 + r * NS)] = a[r];
+    }
+  }
+  if constexpr (!LAST) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = buf[lds_pad(t + m * T)];
+    __syncthreads();
+  }
+}
+
+// In: v[m] = x[t + m*T].  Out: v[m] = X[t + m*T], X = forward DFT (exp(-2 pi i nk/N)).
+// Every thread of the workgroup must call it (block-wide barriers inside).
+template <int N>
+__device__ __forceinline__ void fft_lanes(float2 (&v)[8], const float2 (&tw)[TwN<N>::total], int t, float2* buf) {
+  using P = Plan<N>;
+  fft_stage<N, P::r0, 1, false, 0>(v, tw, t, buf);
+  if constexpr (P::n == 2) {
+    fft_stage<N, P::r1, P::r0, true, TwN<N>::off1>(v, tw, t, buf);
+  } else if constexpr (P::n == 3) {
+    fft_stage<N, P::r1, P::r0, false, TwN<N>::off1>(v, tw, t, buf);
+    fft_stage<N, P::r2, P::r0 * P::r1, true, TwN<N>::off2>(v, tw, t, buf);
+  } else {
+    fft_stage<N, P::r1, P::r0, false, TwN<N>::off1>(v, tw, t, buf);
+    fft_stage<N, P::r2, P::r0 * P::r1, false, TwN<N>::off2>(v, tw, t, buf);
+    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, TwN<N>::off3>(v, tw, t, buf);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// lattice geometry
+// ------------------------------------------------------------------------------------------
+struct DevGeom {
+  double height;      // nx * apix (utils.py:180)
+  float apix, inv_apix;
+  float inv_sigma2;   // ln2 / ball_radius^2
+  float dy;
+  float m[6];         // rows 1 (image row axis) and 2 (helical axis) of R_yx(tilt, -psi)
+  int rpx;            // truncation half-window, pixels
+  int n_units;
+  int has_rot;
+  int pad_;
+};
+
+struct Cand {  // one candidate, decoded once per workgroup
+  double twist, rise, rot;
+  int csym, imax, M;
+};
+
+__device__ __forceinline__ Cand decode_candidate(const double* __restrict__ p, const DevGeom& g) {
+  Cand c;
+  c.twist = p[0];
+  c.rise = p[1];
+  c.csym = (int)p[2];
+  c.rot = p[3];
+  if (c.csym < 1) c.csym = 1;
+  if (c.csym > 360) c.csym = 360;
+  double im = ceil(g.height / c.rise);  // utils.py:153
+  if (!(im >= 0.0)) im = -1.0;          // rise <= 0 / NaN: empty lattice
+  if (im > 1048576.0) im = 1048576.0;
+  c.imax = (int)im;
+  c.M = c.imax < 0 ? 0 : (2 * c.imax + 1) * c.csym * g.n_units;
+  return c;
+}
+
+// Centre `ci` of the lattice in Angstrom: (row coordinate, axial coordinate) = utils.py:153-171.
+__device__ __forceinline__ void centre_position(const Cand& c, const DevGeom& g, const float* __restrict__ units,
+                                                int ci, float& yc, float& xc) {
+  const int u = ci % g.n_units;
+  const int is = ci / g.n_units;
+  const int s = is % c.csym;
+  const int i = is / c.csym - c.imax;
+  const float r = units[3 * u], a0 = units[3 * u + 1], z = units[3 * u + 2];
+  double turns = ((double)a0 + c.rot + c.twist * (double)i + (double)s * (360.0 / (double)c.csym)) * (1.0 / 360.0);
+  turns -= floor(turns);
+  float sn, cs;
+  sincospif(2.0f * (float)turns, &sn, &cs);
+  float cu = r * cs, cv = r * sn;
+  float ca = z + (float)((double)i * c.rise);
+  if (g.has_rot) {
+    const float v2 = g.m[0] * cu + g.m[1] * cv + g.m[2] * ca;
+    const float a2 = g.m[3] * cu + g.m[4] * cv + g.m[5] * ca;
+    cv = v2;
+    ca = a2;
+  }
+  yc = cv + g.dy;
+  xc = ca;
+}
+
+// ------------------------------------------------------------------------------------------
+// K_A: raster (or image load) + column FFT, 16 image columns per workgroup
+// ------------------------------------------------------------------------------------------
+struct FirstArgs {
+  const double* params;   // [B][4] (raster mode)
+  const float* units;     // [n_units][3]
+  const float* images;    // [B][N][N] (image mode)
+  const float2* twtab;    // [N]
+  float2* inter;          // [B][N/2][N]
+  float* raster_out;      // optional [B][N][N]
+  DevGeom g;
+};
+
+constexpr int MODE_RASTER = 0, MODE_IMAGE = 1;
+
+template <int N>
+struct KA {
+  static constexpr int T = N / 8;            // lanes per FFT
+  static constexpr int FPW = 8;              // FFTs per workgroup
+  static constexpr int COLS = 2 * FPW;       // image columns per workgroup
+  static constexpr int THREADS = FPW * T;    // == N
+  static constexpr int BUF = N + N / 8;      // padded complex slots per FFT buffer
+  static constexpr int STAGE_ROW = COLS + 2; // complex slots per staging row (+16 B pad)
+  static constexpr size_t LDS = (size_t)FPW * BUF * sizeof(float2);
+  static_assert((size_t)(N / 2) * STAGE_ROW * sizeof(float2) <= LDS, "staging tile must alias the FFT buffers");
+};
+
+template <int N, int MODE>
+__global__ __launch_bounds__(KA<N>::THREADS) void k_first_pass(FirstArgs a) {
+  using K = KA<N>;
+  constexpr int T = K::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* const bufs = reinterpret_cast<float2*>(smem);
+  const int tid = threadIdx.x;
+  const int f = tid / T, t = tid % T;
+  float2* const buf = bufs + f * K::BUF;
+  const int x0 = blockIdx.x * K::COLS;
+  const int xa = x0 + 2 * f;
+  const size_t b = blockIdx.y;
+
+  float2 tw[TwN<N>::total];
+  load_twiddles<N>(tw, t, a.twtab);
+  float2 v[8];
+
+  if constexpr (MODE == MODE_RASTER) {
+    const DevGeom& g = a.g;
+    const Cand c = decode_candidate(a.params + 4 * b, g);
+#pragma unroll
+    for (int m = 0; m < 9; ++m) buf[t + m * T] = make_float2(0.f, 0.f);
+    __syncthreads();
+    // One wavefront (or the T lanes of a narrower group) rasterises the group's two columns:
+    // scan the lattice TL centres at a time, then add every hit's (2R+1) x 2 footprint.
+    constexpr int TL = T < 64 ? T : 64;
+    if (t < TL) {
+      float* const zf = reinterpret_cast<float*>(buf);
+      const int lane = tid & 63;
+      const int gbase = lane - (t & 63);
+      const unsigned long long gmask = TL == 64 ? ~0ull : ((1ull << TL) - 1ull);
+      const int col = t & 1;
+      const float lo = (float)(xa - g.rpx - 1), hi = (float)(xa + 1 + g.rpx + 1);
+      const float qx = (float)(xa + col - N / 2) * g.apix;  // X of utils.py:94-99
+      const float fq = (float)(xa + col);
+      for (int base = 0; base < c.M; base += TL) {
+        bool hit = false;
+        const int ci = base + t;
+        if (ci < c.M) {
+          float yc, xc;
+          centre_position(c, g, a.units, ci, yc, xc);
+          const float cx = xc * g.inv_apix + (float)(N / 2);
+          const float cy = yc * g.inv_apix + (float)(N / 2);
+          hit = (cx >= lo) && (cx <= hi) && (cy >= (float)(-g.rpx - 1)) && (cy <= (float)(N + g.rpx));
+        }
+        unsigned long long todo = (__ballot(hit) >> gbase) & gmask;
+        while (todo) {
+          const int k = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          float yc, xc;
+          centre_position(c, g, a.units, base + k, yc, xc);
+          const float cx = xc * g.inv_apix + (float)(N / 2);
+          const float cy = yc * g.inv_apix + (float)(N / 2);
+          const float dx = qx - xc;
+          const bool colok = fabsf(fq - cx) <= (float)g.rpx;
+          const int y0 = (int)ceilf(cy - (float)g.rpx);
+          for (int ro = t >> 1; ro <= 2 * g.rpx; ro += TL / 2) {
+            const int y = y0 + ro;
+            if (colok && y >= 0 && y < N && fabsf((float)y - cy) <= (float)g.rpx) {
+              const float dyv = (float)(y - N / 2) * g.apix - yc;
+              zf[2 * lds_pad(y) + col] += __expf(-(dx * dx + dyv * dyv) * g.inv_sigma2);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = buf[lds_pad(t + m * T)];
+    if (a.raster_out != nullptr) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        *reinterpret_cast<float2*>(a.raster_out + (b * N + (size_t)(t + m * T)) * N + xa) = v[m];
+    }
+    __syncthreads();
+  } else {
+    const float* img = a.images + b * (size_t)N * N;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = *reinterpret_cast<const float2*>(img + (size_t)(t + m * T) * N + xa);
+  }
+
+  fft_lanes<N>(v, tw, t, buf);  // v[m] = Z[t + m*T], Z = DFT_y(col_a + i col_b)
+
+  // Split Z into the two real columns' spectra: A[k] = (Z[k] + conj Z[N-k]) / 2,
+  // B[k] = (Z[k] - conj Z[N-k]) / (2i), k < N/2; ky = 0 and ky = N/2 (both real) share row 0.
+#pragma unroll
+  for (int m = 0; m < 8; ++m) buf[lds_pad(t + m * T)] = v[m];
+  __syncthreads();
+  float4 ab[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = t + m * T;
+    const float2 zk = v[m];
+    const float2 zm = buf[lds_pad((N - k) & (N - 1))];
+    ab[m] = make_float4(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y), 0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+  }
+  if (t == 0) ab[0] = make_float4(v[0].x, v[4].x, v[0].y, v[4].y);
+  __syncthreads();  // every group is done with its FFT buffer: reuse LDS as the staging tile
+  float2* const stage = bufs;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = t + m * T;
+    *reinterpret_cast<float4*>(stage + k * K::STAGE_ROW + 2 * f) = ab[m];
+  }
+  __syncthreads();
+  float2* const out = a.inter + b * (size_t)(N / 2) * N + x0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = p * K::THREADS + tid;  // (N/2) rows x 8 float4
+    const int row = idx >> 3, c4 = idx & 7;
+    const float4 val = *reinterpret_cast<const float4*>(stage + row * K::STAGE_ROW + 2 * c4);
+    *reinterpret_cast<float4*>(out + (size_t)row * N + 2 * c4) = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_B: row FFT + amplitude + masked moments (or: store the half-plane spectrum)
+// ------------------------------------------------------------------------------------------
+struct SecondArgs {
+  const float2* inter;    // [B][N/2][N]
+  const float2* twtab;    // [N]
+  const float2* w2;       // [N/2+1][N] {w, w*(E-Ebar)}       (EPI_SCORE)
+  double* partials;       // [B][NBLK][3]                      (EPI_SCORE)
+  float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
+  int log_flag;
+};
+
+constexpr int EPI_SCORE = 0, EPI_STORE = 1;
+
+template <int N>
+struct KB {
+  static constexpr int T = N / 8;
+  static constexpr int ROWS = N / 2;
+  static constexpr int THREADS = (ROWS * T < 256) ? ROWS * T : 256;
+  static constexpr int GROUPS = THREADS / T;
+  static constexpr int RPW = ROWS < 32 ? ROWS : 32;  // rows per workgroup
+  static constexpr int ITERS = RPW / GROUPS;
+  static constexpr int NBLK = ROWS / RPW;
+  static constexpr int BUF = N + N / 8;
+  static constexpr size_t LDS = (size_t)GROUPS * BUF * sizeof(float2);
+  static_assert(ITERS >= 1 && ITERS * GROUPS == RPW, "row tiling");
+};
+
+__device__ __forceinline__ float amp_to_q(float2 f, int log_flag) {
+  const float a = sqrtf(f.x * f.x + f.y * f.y);
+  return log_flag ? log1pf(a) : a;
+}
+
+template <int N, int EPI>
+__global__ __launch_bounds__(KB<N>::THREADS) void k_second_pass(SecondArgs a) {
+  using K = KB<N>;
+  constexpr int T = K::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* const bufs = reinterpret_cast<float2*>(smem);
+  const int tid = threadIdx.x;
+  const int gi = tid / T, t = tid % T;
+  float2* const buf = bufs + gi * K::BUF;
+  const size_t b = blockIdx.y;
+  const float2* const in = a.inter + b * (size_t)K::ROWS * N;
+
+  float2 tw[TwN<N>::total];
+  load_twiddles<N>(tw, t, a.twtab);
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+
+#pragma unroll 1
+  for (int it = 0; it < K::ITERS; ++it) {
+    const int row = blockIdx.x * K::RPW + it * K::GROUPS + gi;
+    const float2* const src = in + (size_t)row * N;
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = src[t + m * T];
+    fft_lanes<N>(v, tw, t, buf);  // v[m] = C[kx = t + m*T]
+
+    if (blockIdx.x == 0 && it == 0) {
+      // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]).
+      // (workgroup-uniform branch: all groups take the barriers, group 0 uses the result)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) buf[lds_pad(t + m * T)] = v[m];
+      __syncthreads();
+      if (gi == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int kx = t + m * T;
+          const float2 ck = v[m];
+          const float2 cm = buf[lds_pad((N - kx) & (N - 1))];
+          const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
+          const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
+          if constexpr (EPI == EPI_SCORE) {
+            const float2 w0 = a.w2[kx];
+            const float2 wn = a.w2[(size_t)(N / 2) * N + kx];
+            const float q0 = amp_to_q(f0, a.log_flag), qn = amp_to_q(fn, a.log_flag);
+            s1 += w0.x * q0 + wn.x * qn;
+            s2 += w0.x * q0 * q0 + wn.x * qn * qn;
+            s3 += w0.y * q0 + wn.y * qn;
+          } else {
+            float2* const so = a.spec_out + b * (size_t)(N / 2 + 1) * N;
+            so[kx] = f0;
+            so[(size_t)(N / 2) * N + kx] = fn;
+          }
+        }
+      }
+      __syncthreads();
+      if (gi == 0) continue;
+    }
+    if constexpr (EPI == EPI_SCORE) {
+      const float2* const wrow = a.w2 + (size_t)row * N;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float2 w = wrow[t + m * T];
+        const float q = amp_to_q(v[m], a.log_flag);
+        s1 += w.x * q;
+        s2 += w.x * q * q;
+        s3 += w.y * q;
+      }
+    } else {
+      float2* const so = a.spec_out + (b * (size_t)(N / 2 + 1) + row) * N;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) so[t + m * T] = v[m];
+    }
+  }
+
+  if constexpr (EPI == EPI_SCORE) {
+    // float partials (<= 64 terms per lane) -> float64 wave shuffle reduce -> LDS -> one triple
+    double d1 = s1, d2 = s2, d3 = s3;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      d1 += __shfl_down(d1, off, 64);
+      d2 += __shfl_down(d2, off, 64);
+      d3 += __shfl_down(d3, off, 64);
+    }
+    __syncthreads();
+    double* const red = reinterpret_cast<double*>(smem);
+    constexpr int NW = (K::THREADS + 63) / 64;
+    if ((tid & 63) == 0) {
+      red[3 * (tid >> 6)] = d1;
+      red[3 * (tid >> 6) + 1] = d2;
+      red[3 * (tid >> 6) + 2] = d3;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double r1 = 0, r2 = 0, r3 = 0;
+      for (int w = 0; w < NW; ++w) {
+        r1 += red[3 * w];
+        r2 += red[3 * w + 1];
+        r3 += red[3 * w + 2];
+      }
+      double* const o = a.partials + (b * K::NBLK + blockIdx.x) * 3;
+      o[0] = r1;
+      o[1] = r2;
+      o[2] = r3;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K_C: Pearson from moments
+// ------------------------------------------------------------------------------------------
+struct RefConsts {
+  double sw;     // sum of weights = number of masked bins on the full plane
+  double swec;   // sum of the float32-rounded w*(E-Ebar) (exactly what K_B multiplies by)
+  double var_e;  // sum w (E-Ebar)^2
+};
+
+__global__ void k_finalize(const double* __restrict__ partials, int nblk, int64_t n, RefConsts rc,
+                           float* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s1 = 0, s2 = 0, s3 = 0;
+  for (int k = 0; k < nblk; ++k) {
+    const double* p = partials + (i * nblk + k) * 3;
+    s1 += p[0];
+    s2 += p[1];
+    s3 += p[2];
+  }
+  double score = 0.0;
+  if (rc.sw > 0) {
+    const double var_q = s2 - s1 * s1 / rc.sw;
+    const double cov = s3 - (s1 / rc.sw) * rc.swec;
+    const double den = var_q * rc.var_e;
+    // analysis.py:796-797: zero variance -> 0.  The float32 moments leave O(1e-7) relative
+    // rounding in var_q, so "zero" is a relative test.
+    if (den > 0 && var_q > 1e-9 * s2) score = cov / sqrt(den);
+  }
+  scores[i] = (float)score;
+}
+
+// ------------------------------------------------------------------------------------------
+// spectrum expansion for hh_power_spectrum, and the vector reductions
+// ------------------------------------------------------------------------------------------
+__global__ void k_expand_spectrum(const float2* __restrict__ spec, int n, int log_flag, float* __restrict__ pwr,
+                                  float* __restrict__ phase, unsigned* __restrict__ minmax) {
+  const int iy = blockIdx.x;
+  const int uy = (iy + n / 2) & (n - 1);  // unshifted frequency index
+  float lmin = INFINITY, lmax = 0.f;
+  for (int ix = threadIdx.x; ix < n; ix += blockDim.x) {
+    const int ux = (ix + n / 2) & (n - 1);
+    float2 f;
+    if (uy <= n / 2) {
+      f = spec[(size_t)uy * n + ux];
+    } else {
+      f = spec[(size_t)(n - uy) * n + ((n - ux) & (n - 1))];
+      f.y = -f.y;
+    }
+    const float a = sqrtf(f.x * f.x + f.y * f.y);
+    const float q = log_flag ? log1pf(a) : a;
+    pwr[(size_t)iy * n + ix] = q;
+    if (phase) phase[(size_t)iy * n + ix] = atan2f(f.y, f.x);
+    lmin = fminf(lmin, q);
+    lmax = fmaxf(lmax, q);
+  }
+  // q >= 0, so the IEEE bit patterns order like unsigned integers
+  atomicMin(&minmax[0], __float_as_uint(lmin));
+  atomicMax(&minmax[1], __float_as_uint(lmax));
+}
+
+__global__ void k_normalise(float* __restrict__ pwr, size_t n, const unsigned* __restrict__ minmax) {
+  const float vmin = __uint_as_float(minmax[0]), vmax = __uint_as_float(minmax[1]);
+  if (vmax == vmin) return;  // filters.py:278-279
+  const float inv = 1.0f / (vmax - vmin);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    pwr[i] = (pwr[i] - vmin) * inv;
+}
+
+template <typename T>
+__global__ void k_pair_sums(const T* __restrict__ x, const T* __restrict__ y, int64_t n, double mx, double my,
+                            double* __restrict__ out /*[grid][5]*/) {
+  double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double p = (double)x[i] - mx, q = (double)y[i] - my;
+    sx += p;
+    sy += q;
+    sxx += p * p;
+    syy += q * q;
+    sxy += p * q;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sx += __shfl_down(sx, off, 64);
+    sy += __shfl_down(sy, off, 64);
+    sxx += __shfl_down(sxx, off, 64);
+    syy += __shfl_down(syy, off, 64);
+    sxy += __shfl_down(sxy, off, 64);
+  }
+  __shared__ double red[4][5];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[w][0] = sx; red[w][1] = sy; red[w][2] = sxx; red[w][3] = syy; red[w][4] = sxy;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double r = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += red[k][threadIdx.x];
+    out[blockIdx.x * 5 + threadIdx.x] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t a, b;
+  int kind;
+};
+
+}  // namespace
+
+struct hh_ctx {
+  int device = 0;
+  int n = 0;
+  int max_batch = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  float2* d_tw = nullptr;
+  float2* d_inter = nullptr;     // [max_batch][N/2][N]
+  double* d_partials = nullptr;  // [max_batch][NBLK][3]
+  double* d_params = nullptr;    // staging for hh_sweep
+  float* d_scores = nullptr;
+  int64_t cap_params = 0;
+  float* d_units = nullptr;
+  float2* d_w2 = nullptr;        // [S][N/2+1][N]
+  float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
+  int64_t cap_spec = 0;
+  float* d_img = nullptr;        // scratch images
+  int64_t cap_img = 0;
+  std::vector<RefConsts> ref;
+  int n_segments = 0;
+  int log_flag = 1;
+  bool have_geom = false;
+  DevGeom geom{};
+
+  bool profiling = false;
+  std::vector<EventPair> events;
+  size_t events_used = 0;
+  int64_t prof_candidates = 0;
+};
+
+namespace {
+
+int fail(hh_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HH_HIP(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(ctx, HH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));            \
+  } while (0)
+
+bool supported_n(int n) { return n == 32 || n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
+
+int nblk_for(int n) {
+  switch (n) {
+    case 32: return KB<32>::NBLK;
+    case 64: return KB<64>::NBLK;
+    case 128: return KB<128>::NBLK;
+    case 256: return KB<256>::NBLK;
+    case 512: return KB<512>::NBLK;
+    default: return KB<1024>::NBLK;
+  }
+}
+
+struct ProfScope {  // hipEvent pair around one launch when profiling is on
+  hh_ctx* c;
+  EventPair* ep = nullptr;
+  ProfScope(hh_ctx* ctx, int kind) : c(ctx) {
+    if (!c->profiling) return;
+    if (c->events_used == c->events.size()) {
+      EventPair p{};
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+      c->events.push_back(p);
+    }
+    ep = &c->events[c->events_used++];
+    ep->kind = kind;
+    (void)hipEventRecord(ep->a, c->stream);
+  }
+  ~ProfScope() {
+    if (ep) (void)hipEventRecord(ep->b, c->stream);
+  }
+};
+
+template <int N, int MODE>
+int launch_first(hh_ctx* c, const FirstArgs& a, int batch) {
+  using K = KA<N>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_first_pass<N, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    attr_done = true;
+  }
+  ProfScope ps(c, 0);
+  hipLaunchKernelGGL((k_first_pass<N, MODE>), dim3(N / K::COLS, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  HH_HIP(c, hipGetLastError());
+  return HH_OK;
+}
+
+template <int N, int EPI>
+int launch_second(hh_ctx* c, const SecondArgs& a, int batch) {
+  using K = KB<N>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_second_pass<N, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    attr_done = true;
+  }
+  ProfScope ps(c, 1);
+  hipLaunchKernelGGL((k_second_pass<N, EPI>), dim3(K::NBLK, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  HH_HIP(c, hipGetLastError());
+  return HH_OK;
+}
+
+template <int MODE>
+int dispatch_first(hh_ctx* c, const FirstArgs& a, int batch) {
+  switch (c->n) {
+    case 32: return launch_first<32, MODE>(c, a, batch);
+    case 64: return launch_first<64, MODE>(c, a, batch);
+    case 128: return launch_first<128, MODE>(c, a, batch);
+    case 256: return launch_first<256, MODE>(c, a, batch);
+    case 512: return launch_first<512, MODE>(c, a, batch);
+    case 1024: return launch_first<1024, MODE>(c, a, batch);
+  }
+  return fail(c, HH_ERR_ARG, "unsupported image size");
+}
+
+template <int EPI>
+int dispatch_second(hh_ctx* c, const SecondArgs& a, int batch) {
+  switch (c->n) {
+    case 32: return launch_second<32, EPI>(c, a, batch);
+    case 64: return launch_second<64, EPI>(c, a, batch);
+    case 128: return launch_second<128, EPI>(c, a, batch);
+    case 256: return launch_second<256, EPI>(c, a, batch);
+    case 512: return launch_second<512, EPI>(c, a, batch);
+    case 1024: return launch_second<1024, EPI>(c, a, batch);
+  }
+  return fail(c, HH_ERR_ARG, "unsupported image size");
+}
+
+int ensure_img(hh_ctx* c, int64_t count) {
+  const int64_t need = count * (int64_t)c->n * c->n;
+  if (need <= c->cap_img) return HH_OK;
+  if (c->d_img) HH_HIP(c, hipFree(c->d_img));
+  c->d_img = nullptr;
+  c->cap_img = 0;
+  HH_HIP(c, hipMalloc(&c->d_img, need * sizeof(float)));
+  c->cap_img = need;
+  return HH_OK;
+}
+
+int ensure_spec(hh_ctx* c, int64_t count) {
+  const int64_t need = count * (int64_t)(c->n / 2 + 1) * c->n;
+  if (need <= c->cap_spec) return HH_OK;
+  if (c->d_spec) HH_HIP(c, hipFree(c->d_spec));
+  c->d_spec = nullptr;
+  c->cap_spec = 0;
+  HH_HIP(c, hipMalloc(&c->d_spec, need * sizeof(float2)));
+  c->cap_spec = need;
+  return HH_OK;
+}
+
+// images already in c->d_img ([count][N][N]); leaves the half-plane spectra in c->d_spec
+int spectra_of_images(hh_ctx* c, int count) {
+  int rc = ensure_spec(c, count);
+  if (rc) return rc;
+  for (int s0 = 0; s0 < count; s0 += c->max_batch) {
+    const int nb = std::min(c->max_batch, count - s0);
+    FirstArgs fa{};
+    fa.images = c->d_img + (size_t)s0 * c->n * c->n;
+    fa.twtab = c->d_tw;
+    fa.inter = c->d_inter;
+    fa.g = c->geom;
+    rc = dispatch_first<MODE_IMAGE>(c, fa, nb);
+    if (rc) return rc;
+    SecondArgs sa{};
+    sa.inter = c->d_inter;
+    sa.twtab = c->d_tw;
+    sa.spec_out = c->d_spec + (size_t)s0 * (c->n / 2 + 1) * c->n;
+    rc = dispatch_second<EPI_STORE>(c, sa, nb);
+    if (rc) return rc;
+  }
+  return HH_OK;
+}
+
+int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
+  const int nblk = nblk_for(c->n);
+  for (int64_t g0 = 0; g0 < g; g0 += c->max_batch) {
+    const int nb = (int)std::min<int64_t>(c->max_batch, g - g0);
+    FirstArgs fa{};
+    fa.params = d_params + 4 * g0;
+    fa.units = c->d_units;
+    fa.twtab = c->d_tw;
+    fa.inter = c->d_inter;
+    fa.g = c->geom;
+    int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
+    if (rc) return rc;
+    for (int s = 0; s < c->n_segments; ++s) {
+      SecondArgs sa{};
+      sa.inter = c->d_inter;
+      sa.twtab = c->d_tw;
+      sa.w2 = c->d_w2 + (size_t)s * (c->n / 2 + 1) * c->n;
+      sa.partials = c->d_partials;
+      sa.log_flag = c->log_flag;
+      rc = dispatch_second<EPI_SCORE>(c, sa, nb);
+      if (rc) return rc;
+      {
+        ProfScope ps(c, 2);
+        hipLaunchKernelGGL(k_finalize, dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
+                           (int64_t)nb, c->ref[s], d_scores + (size_t)s * g + g0);
+      }
+      HH_HIP(c, hipGetLastError());
+    }
+  }
+  c->prof_candidates += g;
+  return HH_OK;
+}
+
+int check_ready(hh_ctx* c, bool need_ref) {
+  if (!c) return HH_ERR_ARG;
+  if (!c->have_geom) return fail(c, HH_ERR_STATE, "hh_set_geometry has not been called");
+  if (need_ref && c->n_segments == 0) return fail(c, HH_ERR_STATE, "hh_set_reference has not been called");
+  return HH_OK;
+}
+
+template <typename T>
+int pair_reduce(hh_ctx* c, const T* a, const T* b, int64_t n, double mx, double my, double out[5]) {
+  const int grid = (int)std::min<int64_t>(1024, (n + 255) / 256);
+  T *da = nullptr, *db = nullptr;
+  double* dp = nullptr;
+  HH_HIP(c, hipMalloc(&da, n * sizeof(T)));
+  HH_HIP(c, hipMalloc(&db, n * sizeof(T)));
+  HH_HIP(c, hipMalloc(&dp, (size_t)grid * 5 * sizeof(double)));
+  std::vector<double> hp((size_t)grid * 5);
+  hipError_t e = hipMemcpyAsync(da, a, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, b, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((k_pair_sums<T>), dim3(grid), dim3(256), 0, c->stream, da, db, n, mx, my, dp);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), dp, hp.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dp);
+  if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("pair_reduce: ") + hipGetErrorString(e));
+  for (int k = 0; k < 5; ++k) out[k] = 0;
+  for (int g = 0; g < grid; ++g)
+    for (int k = 0; k < 5; ++k) out[k] += hp[(size_t)g * 5 + k];
+  return HH_OK;
+}
+
+// Two passes like analysis.py:793-799: means first, then the centred sums.
+template <typename T>
+int pearson(hh_ctx* c, const T* a, const T* b, int64_t n, double* out) {
+  if (!c || !a || !b || !out || n <= 0) return fail(c, HH_ERR_ARG, "cross_correlation: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  double s[5];
+  int rc = pair_reduce(c, a, b, n, 0.0, 0.0, s);
+  if (rc) return rc;
+  const double mx = s[0] / (double)n, my = s[1] / (double)n;
+  rc = pair_reduce(c, a, b, n, mx, my, s);
+  if (rc) return rc;
+  const double norm = std::sqrt(s[2] * s[3]);
+  *out = norm == 0 ? 0.0 : s[4] / norm;
+  return HH_OK;
+}
+
+template <typename T>
+int cosine(hh_ctx* c, const T* a, const T* b, int64_t n, double* out) {
+  if (!c || !a || !b || !out || n <= 0) return fail(c, HH_ERR_ARG, "cosine_similarity: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  double s[5];
+  int rc = pair_reduce(c, a, b, n, 0.0, 0.0, s);
+  if (rc) return rc;
+  const double norm = std::sqrt(s[2]) * std::sqrt(s[3]);
+  *out = norm == 0 ? 0.0 : s[4] / norm;
+  return HH_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int hh_abi_version(void) { return HH_ABI_VERSION; }
+
+int hh_device_count(int* count) {
+  if (!count) return HH_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, HH_ERR_HIP, "hipGetDeviceCount failed");
+  }
+  *count = n;
+  return HH_OK;
+}
+
+int64_t hh_algorithmic_bytes(int n) { return 4LL * n * n + 16LL * n * (n / 2 + 1); }
+
+const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hh_create(hh_ctx** out, int device, int n, int max_batch) {
+  if (!out) return fail(nullptr, HH_ERR_ARG, "hh_create: out is NULL");
+  *out = nullptr;
+  if (!supported_n(n)) return fail(nullptr, HH_ERR_ARG, "hh_create: image side must be a power of two in [32, 1024]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, HH_ERR_HIP, "hh_create: no HIP device is visible (the sweep has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, HH_ERR_ARG, "hh_create: device ordinal out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return fail(nullptr, HH_ERR_HIP, "hh_create: hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, HH_ERR_HIP, std::string("hh_create: built for gfx950 only, device is ") + prop.gcnArchName);
+  if (max_batch <= 0) {
+    // keep one batch of half spectra (N^2 * 4 B each) around 128 MiB: inside the 256 MiB
+    // Infinity Cache together with the streaming traffic of the two passes
+    max_batch = (int)std::max<int64_t>(16, (128LL << 20) / ((int64_t)n * n * 4));
+    max_batch = std::min(max_batch, 4096);
+  }
+  if (max_batch > 65535) max_batch = 65535;  // gridDim.y
+  hh_ctx* c = new (std::nothrow) hh_ctx();
+  if (!c) return fail(nullptr, HH_ERR_NOMEM, "hh_create: out of host memory");
+  c->device = device;
+  c->n = n;
+  c->max_batch = max_batch;
+  auto bail = [&](int code, const std::string& msg) {
+    g_create_error = msg;
+    hh_destroy(c);
+    return code;
+  };
+#define HH_CREATE_HIP(call)                                                                     \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess) return bail(HH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+  HH_CREATE_HIP(hipSetDevice(device));
+  HH_CREATE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HH_CREATE_HIP(hipMalloc(&c->d_tw, (size_t)n * sizeof(float2)));
+  HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
+  HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)max_batch * nblk_for(n) * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(float)));
+  std::vector<float2> tw((size_t)n);
+  for (int k = 0; k < n; ++k) {
+    const double ang = -2.0 * M_PI * (double)k / (double)n;
+    tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  HH_CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+#undef HH_CREATE_HIP
+  *out = c;
+  return HH_OK;
+}
+
+void hh_destroy(hh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (auto& e : c->events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  (void)hipFree(c->d_tw);
+  (void)hipFree(c->d_inter);
+  (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_params);
+  (void)hipFree(c->d_scores);
+  (void)hipFree(c->d_units);
+  (void)hipFree(c->d_w2);
+  (void)hipFree(c->d_spec);
+  (void)hipFree(c->d_img);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int hh_max_batch(const hh_ctx* c) { return c ? c->max_batch : HH_ERR_ARG; }
+
+int hh_set_stream(hh_ctx* c, void* hip_stream) {
+  if (!c) return HH_ERR_ARG;
+  HH_HIP(c, hipSetDevice(c->device));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return HH_OK;
+}
+
+int hh_synchronize(hh_ctx* c) {
+  if (!c) return HH_ERR_ARG;
+  HH_HIP(c, hipSetDevice(c->device));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  return HH_OK;
+}
+
+int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
+  if (!c || !g) return fail(c, HH_ERR_ARG, "hh_set_geometry: NULL argument");
+  if (!(g->apix > 0) || !(g->ball_radius > 0) || !(g->helical_diameter >= 0))
+    return fail(c, HH_ERR_ARG, "hh_set_geometry: apix and ball_radius must be positive");
+  // utils.py:88
+  if (!(g->helical_diameter + g->ball_radius < c->n * g->apix * 0.99))
+    return fail(c, HH_ERR_ARG, "hh_set_geometry: helical_diameter + ball_radius must be < 0.99 * ny * apix");
+  if (g->n_units < 0 || g->n_units > HH_MAX_UNITS) return fail(c, HH_ERR_ARG, "hh_set_geometry: n_units out of range");
+  if (g->n_units > 1 && !g->units) return fail(c, HH_ERR_ARG, "hh_set_geometry: units is NULL");
+  HH_HIP(c, hipSetDevice(c->device));
+  DevGeom d{};
+  d.height = (double)c->n * g->apix;
+  d.apix = (float)g->apix;
+  d.inv_apix = (float)(1.0 / g->apix);
+  const double sigma2 = g->ball_radius * g->ball_radius / std::log(2.0);
+  d.inv_sigma2 = (float)(1.0 / sigma2);
+  d.dy = (float)g->dy;
+  const int bits = g->tail_bits > 0 ? g->tail_bits : 24;
+  // exp(-(R*apix)^2 / sigma2) < 2^-bits
+  d.rpx = (int)std::ceil(std::sqrt(sigma2 * bits * std::log(2.0)) / g->apix);
+  if (d.rpx < 1) d.rpx = 1;
+  if (d.rpx > c->n) d.rpx = c->n;
+  d.has_rot = (g->tilt != 0.0 || g->psi != 0.0) ? 1 : 0;
+  {
+    // R = Rx(-psi) * Ry(tilt) (scipy from_euler("yx", (tilt, -psi)), utils.py:167); rows 1, 2
+    const double a = g->tilt * M_PI / 180.0, b = -g->psi * M_PI / 180.0;
+    const double ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b);
+    d.m[0] = (float)(sb * sa);  d.m[1] = (float)cb;  d.m[2] = (float)(-sb * ca);
+    d.m[3] = (float)(-cb * sa); d.m[4] = (float)sb;  d.m[5] = (float)(cb * ca);
+  }
+  std::vector<float> units;
+  if (g->n_units <= 1 && !g->units) {
+    units = {(float)(g->helical_diameter / 2.0), 0.f, 0.f};
+    d.n_units = 1;
+  } else {
+    d.n_units = std::max(1, g->n_units);
+    units.assign(g->units, g->units + 3 * (size_t)d.n_units);
+  }
+  HH_HIP(c, hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  c->geom = d;
+  c->have_geom = true;
+  return HH_OK;
+}
+
+int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8_t* mask, int log_flag) {
+  if (!c || !images || !mask || n_segments <= 0) return fail(c, HH_ERR_ARG, "hh_set_reference: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  const int n = c->n;
+  const size_t npix = (size_t)n * n, nh = (size_t)(n / 2 + 1) * n;
+  int rc = ensure_img(c, n_segments);
+  if (rc) return rc;
+  HH_HIP(c, hipMemcpyAsync(c->d_img, images, (size_t)n_segments * npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  rc = spectra_of_images(c, n_segments);
+  if (rc) return rc;
+  std::vector<float2> spec((size_t)n_segments * nh);
+  HH_HIP(c, hipMemcpyAsync(spec.data(), c->d_spec, spec.size() * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+
+  // Hermitian half-plane weights: W[ky][kx] = mask(k) + mask(-k) for 0 < ky < N/2, mask(k) on
+  // the two self-paired rows ky = 0 and ky = N/2 (both members of a pair lie in the half plane).
+  std::vector<float> w(nh);
+  double sw = 0;
+  auto mu = [&](int uy, int ux) {  // mask at unshifted frequency indices
+    return mask[(size_t)((uy + n / 2) & (n - 1)) * n + ((ux + n / 2) & (n - 1))] ? 1.f : 0.f;
+  };
+  for (int ky = 0; ky <= n / 2; ++ky)
+    for (int kx = 0; kx < n; ++kx) {
+      float v = mu(ky, kx);
+      if (ky > 0 && ky < n / 2) v += mu((n - ky) & (n - 1), (n - kx) & (n - 1));
+      w[(size_t)ky * n + kx] = v;
+      sw += v;
+    }
+  if (!(sw > 0)) return fail(c, HH_ERR_ARG, "hh_set_reference: the mask selects no Fourier bin");
+
+  std::vector<float2> w2((size_t)n_segments * nh);
+  c->ref.assign(n_segments, RefConsts{});
+  std::vector<double> e(nh);
+  for (int s = 0; s < n_segments; ++s) {
+    const float2* sp = spec.data() + (size_t)s * nh;
+    double se = 0;
+    for (size_t i = 0; i < nh; ++i) {
+      const double a = std::hypot((double)sp[i].x, (double)sp[i].y);
+      e[i] = log_flag ? std::log1p(a) : a;
+      se += (double)w[i] * e[i];
+    }
+    const double ebar = se / sw;
+    double swec = 0, var_e = 0;
+    for (size_t i = 0; i < nh; ++i) {
+      const double dc = e[i] - ebar;
+      const float wec = (float)((double)w[i] * dc);
+      w2[(size_t)s * nh + i] = make_float2(w[i], wec);
+      swec += (double)wec;
+      var_e += (double)w[i] * dc * dc;
+    }
+    c->ref[s] = RefConsts{sw, swec, var_e};
+  }
+  if (c->d_w2) HH_HIP(c, hipFree(c->d_w2));
+  c->d_w2 = nullptr;
+  HH_HIP(c, hipMalloc(&c->d_w2, w2.size() * sizeof(float2)));
+  HH_HIP(c, hipMemcpyAsync(c->d_w2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  c->n_segments = n_segments;
+  c->log_flag = log_flag ? 1 : 0;
+  return HH_OK;
+}
+
+int hh_sweep_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (!d_params || !d_scores || g < 0) return fail(c, HH_ERR_ARG, "hh_sweep_device: bad argument");
+  if (g == 0) return HH_OK;
+  HH_HIP(c, hipSetDevice(c->device));
+  return sweep_on_device(c, d_params, g, d_scores);
+}
+
+int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (!params || !scores || g < 0) return fail(c, HH_ERR_ARG, "hh_sweep: bad argument");
+  if (g == 0) return HH_OK;
+  HH_HIP(c, hipSetDevice(c->device));
+  if (g > c->cap_params) {
+    if (c->d_params) HH_HIP(c, hipFree(c->d_params));
+    if (c->d_scores) HH_HIP(c, hipFree(c->d_scores));
+    c->d_params = nullptr;
+    c->d_scores = nullptr;
+    c->cap_params = 0;
+    HH_HIP(c, hipMalloc(&c->d_params, (size_t)g * 4 * sizeof(double)));
+    HH_HIP(c, hipMalloc(&c->d_scores, (size_t)g * sizeof(float) * 1));
+    c->cap_params = g;
+  }
+  // scores for all segments: S x G
+  float* d_sc = nullptr;
+  if (c->n_segments > 1) {
+    HH_HIP(c, hipMalloc(&d_sc, (size_t)g * c->n_segments * sizeof(float)));
+  } else {
+    d_sc = c->d_scores;
+  }
+  hipError_t e = hipMemcpyAsync(c->d_params, params, (size_t)g * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rc = sweep_on_device(c, c->d_params, g, d_sc);
+    if (rc == HH_OK) {
+      e = hipMemcpyAsync(scores, d_sc, (size_t)g * c->n_segments * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+  }
+  if (c->n_segments > 1) (void)hipFree(d_sc);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_sweep: ") + hipGetErrorString(e));
+  return HH_OK;
+}
+
+int hh_argmax(const float* scores, int64_t n, int64_t* index) {
+  if (!scores || !index || n <= 0) return HH_ERR_ARG;
+  int64_t best = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (scores[i] != scores[i]) continue;  // NaN never wins
+    if (best < 0 || scores[i] > scores[best]) best = i;
+  }
+  *index = best < 0 ? 0 : best;
+  return HH_OK;
+}
+
+int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (!params || !image_out) return fail(c, HH_ERR_ARG, "hh_simulate: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)c->n * c->n;
+  rc = ensure_img(c, 1);
+  if (rc) return rc;
+  double* dp = nullptr;
+  HH_HIP(c, hipMalloc(&dp, 4 * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(dp, params, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    FirstArgs fa{};
+    fa.params = dp;
+    fa.units = c->d_units;
+    fa.twtab = c->d_tw;
+    fa.inter = c->d_inter;
+    fa.raster_out = c->d_img;
+    fa.g = c->geom;
+    rc = dispatch_first<MODE_RASTER>(c, fa, 1);
+    if (rc == HH_OK) {
+      e = hipMemcpyAsync(image_out, c->d_img, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+  }
+  (void)hipFree(dp);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_simulate: ") + hipGetErrorString(e));
+  return HH_OK;
+}
+
+int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_out, float* phase_out) {
+  if (!c || !image || !pwr_out) return fail(c, HH_ERR_ARG, "hh_power_spectrum: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  const int n = c->n;
+  const size_t npix = (size_t)n * n;
+  int rc = ensure_img(c, 3);  // [0] input, [1] pwr, [2] phase
+  if (rc) return rc;
+  HH_HIP(c, hipMemcpyAsync(c->d_img, image, npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  rc = spectra_of_images(c, 1);
+  if (rc) return rc;
+  unsigned* d_mm = nullptr;
+  HH_HIP(c, hipMalloc(&d_mm, 2 * sizeof(unsigned)));
+  const unsigned init[2] = {0x7f800000u, 0u};  // +inf, 0
+  hipError_t e = hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    float* d_pwr = c->d_img + npix;
+    float* d_phase = phase_out ? c->d_img + 2 * npix : nullptr;
+    hipLaunchKernelGGL(k_expand_spectrum, dim3(n), dim3(256), 0, c->stream, c->d_spec, n, log_flag ? 1 : 0, d_pwr,
+                       d_phase, d_mm);
+    hipLaunchKernelGGL(k_normalise, dim3(256), dim3(256), 0, c->stream, d_pwr, npix, d_mm);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(pwr_out, d_pwr, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && phase_out)
+      e = hipMemcpyAsync(phase_out, d_phase, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  (void)hipFree(d_mm);
+  if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_power_spectrum: ") + hipGetErrorString(e));
+  return HH_OK;
+}
+
+int hh_cross_correlation(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return pearson(c, a, b, n, out); }
+int hh_cross_correlation_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return pearson(c, a, b, n, out); }
+int hh_cosine_similarity(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
+int hh_cosine_similarity_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
+
+int hh_profile_enable(hh_ctx* c, int on) {
+  if (!c) return HH_ERR_ARG;
+  c->profiling = on != 0;
+  return HH_OK;
+}
+
+int hh_profile_reset(hh_ctx* c) {
+  if (!c) return HH_ERR_ARG;
+  HH_HIP(c, hipSetDevice(c->device));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  c->events_used = 0;
+  c->prof_candidates = 0;
+  return HH_OK;
+}
+
+int hh_profile_get(hh_ctx* c, hh_profile* out) {
+  if (!c || !out) return HH_ERR_ARG;
+  HH_HIP(c, hipSetDevice(c->device));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  hh_profile p{};
+  for (size_t i = 0; i < c->events_used; ++i) {
+    float ms = 0.f;
+    HH_HIP(c, hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b));
+    switch (c->events[i].kind) {
+      case 0: p.ms_first_pass += ms; p.n_first_pass++; break;
+      case 1: p.ms_second_pass += ms; p.n_second_pass++; break;
+      default: p.ms_finalize += ms; p.n_finalize++; break;
+    }
+  }
+  p.candidates = c->prof_candidates;
+  *out = p;
+  return HH_OK;
+}
+
+}  // extern "C"

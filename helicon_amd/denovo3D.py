@@ -1,0 +1,392 @@
+"""Host mirror of the reference interface for the denovo3D parameter sweep (Path B).
+
+Same names, argument order and return shapes as the reference callables it stands in for:
+
+* ``simulate_helical_projection``   src/helicon/webApps/denovo3D/utils.py:31-189
+* ``compute_power_spectra``         src/helicon/lib/transforms.py:771-820
+* ``cross_correlation_coefficient`` src/helicon/lib/analysis.py:777-799
+* ``cosine_similarity``             src/helicon/lib/analysis.py:802-821
+* ``process_one_task``              src/helicon/webApps/denovo3D/pipeline.py:85-497 (tuple layout)
+* ``sweep`` / ``SweepEngine``       replace the thread pool of app.py:2455-2523
+
+All arithmetic happens in libhelicon_hip.so (hand-written gfx950 kernels) through ctypes;
+there is no NumPy/SciPy fallback — without the library or a GPU these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .grid import CandidateGrid, build_grid, radial_band_mask
+
+__all__ = [
+    "SweepEngine",
+    "SweepResult",
+    "sweep",
+    "simulate_helical_projection",
+    "compute_power_spectra",
+    "cross_correlation_coefficient",
+    "cosine_similarity",
+    "process_one_task",
+    "units_to_cylindrical",
+]
+
+_SUPPORTED_N = (32, 64, 128, 256, 512, 1024)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def units_to_cylindrical(centers_0: np.ndarray) -> np.ndarray:
+    """Cartesian asymmetric-unit positions (columns: projection axis, image-row axis, helical axis —
+    the reference's ``centers_0``, utils.py:138-151) -> (radius A, azimuth deg, axial A) float32."""
+    c = np.asarray(centers_0, dtype=np.float64).reshape(-1, 3)
+    out = np.empty_like(c)
+    out[:, 0] = np.hypot(c[:, 0], c[:, 1])
+    out[:, 1] = np.degrees(np.arctan2(c[:, 1], c[:, 0]))
+    out[:, 2] = c[:, 2]
+    return out.astype(np.float32)
+
+
+class SweepEngine:
+    """One ``hh_ctx``: a device, an image side, device workspaces.  Not thread-safe by itself;
+    calls are serialised with a lock (the reference calls its task function from pool threads)."""
+
+    def __init__(self, n: int, device: int = 0, max_batch: int = 0):
+        if n not in _SUPPORTED_N:
+            raise ValueError(f"image side must be one of {_SUPPORTED_N}, got {n}")
+        self._L = _lib.lib()
+        self._ctx = C.c_void_p()
+        self.n = int(n)
+        self.device = int(device)
+        self._lock = threading.Lock()
+        _lib.check(self._L.hh_create(C.byref(self._ctx), self.device, self.n, int(max_batch)), None)
+        self.max_batch = int(self._L.hh_max_batch(self._ctx))
+        self.n_segments = 0
+        self._geom_key = None
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._L.hh_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        _lib.check(rc, self._ctx)
+
+    # -- configuration ----------------------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        """Run on a caller-owned hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        with self._lock:
+            self._check(self._L.hh_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+
+    def set_geometry(self, *, apix, helical_diameter, ball_radius, tilt=0.0, psi=0.0, dy=0.0,
+                     units=None, tail_bits=0):
+        key = (float(apix), float(helical_diameter), float(ball_radius), float(tilt), float(psi), float(dy),
+               None if units is None else np.asarray(units, dtype=np.float32).tobytes(), int(tail_bits))
+        if key == self._geom_key:
+            return
+        # the reference asserts (utils.py:88); keep its exception type
+        assert helical_diameter + ball_radius < self.n * apix * 0.99
+        g = _lib.hh_geom()
+        g.apix, g.helical_diameter, g.ball_radius = float(apix), float(helical_diameter), float(ball_radius)
+        g.tilt, g.psi, g.dy = float(tilt), float(psi), float(dy)
+        g.tail_bits = int(tail_bits)
+        u = None
+        if units is not None:
+            u = _f32(np.asarray(units).reshape(-1, 3))
+            g.n_units = len(u)
+            g.units = _ptr(u, C.c_float)
+        else:
+            g.n_units = 0
+            g.units = None
+        with self._lock:
+            self._check(self._L.hh_set_geometry(self._ctx, C.byref(g)))
+        self._geom_key = key
+
+    def set_reference(self, images, mask=None, log=True):
+        imgs = _f32(images)
+        if imgs.ndim == 2:
+            imgs = imgs[None]
+        if imgs.ndim != 3 or imgs.shape[1:] != (self.n, self.n):
+            raise ValueError(f"images must be [S, {self.n}, {self.n}], got {imgs.shape}")
+        if mask is None:
+            mask = radial_band_mask(self.n, self.n)
+        m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        if m.shape != (self.n, self.n):
+            raise ValueError(f"mask must be [{self.n}, {self.n}] on the fftshifted plane")
+        with self._lock:
+            self._check(self._L.hh_set_reference(self._ctx, _ptr(imgs, C.c_float), imgs.shape[0],
+                                                 _ptr(m, C.c_uint8), 1 if log else 0))
+        self.n_segments = imgs.shape[0]
+
+    # -- the hot path -----------------------------------------------------------------------
+    def sweep(self, params) -> np.ndarray:
+        """params [G, 4] float64 (twist, rise, csym, rot) -> scores [S, G] float32 (host in, host out)."""
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4)
+        out = np.empty((max(self.n_segments, 1), len(p)), dtype=np.float32)
+        with self._lock:
+            self._check(self._L.hh_sweep(self._ctx, _ptr(p, C.c_double), len(p), _ptr(out, C.c_float)))
+        return out
+
+    def sweep_device(self, d_params: int, n_candidates: int, d_scores: int):
+        """Device pointers (ints): params [G, 4] float64, scores [S, G] float32; asynchronous on
+        the engine's stream."""
+        with self._lock:
+            self._check(self._L.hh_sweep_device(self._ctx, C.c_void_p(d_params), int(n_candidates),
+                                                C.c_void_p(d_scores)))
+
+    def synchronize(self):
+        with self._lock:
+            self._check(self._L.hh_synchronize(self._ctx))
+
+    # -- the primitives ---------------------------------------------------------------------
+    def simulate(self, twist, rise, csym, rot=0.0) -> np.ndarray:
+        p = np.array([twist, rise, csym, rot], dtype=np.float64)
+        out = np.empty((self.n, self.n), dtype=np.float32)
+        with self._lock:
+            self._check(self._L.hh_simulate(self._ctx, _ptr(p, C.c_double), _ptr(out, C.c_float)))
+        return out
+
+    def power_spectrum(self, image, log=True, want_phase=True):
+        img = _f32(image)
+        if img.shape != (self.n, self.n):
+            raise ValueError(f"image must be [{self.n}, {self.n}]")
+        pwr = np.empty((self.n, self.n), dtype=np.float32)
+        phase = np.empty((self.n, self.n), dtype=np.float32) if want_phase else None
+        with self._lock:
+            self._check(self._L.hh_power_spectrum(self._ctx, _ptr(img, C.c_float), 1 if log else 0,
+                                                  _ptr(pwr, C.c_float),
+                                                  _ptr(phase, C.c_float) if want_phase else None))
+        return pwr, phase
+
+    def _pair(self, a, b, f32name, f64name):
+        a = np.asarray(a)
+        b = np.asarray(b)
+        if a.shape != b.shape:
+            raise ValueError("operands must have the same shape")
+        if a.size == 0:
+            return 0
+        out = C.c_double(0.0)
+        if a.dtype == np.float32 and b.dtype == np.float32:
+            x, y = np.ascontiguousarray(a).ravel(), np.ascontiguousarray(b).ravel()
+            fn, ct = getattr(self._L, f32name), C.c_float
+        else:
+            x = np.ascontiguousarray(a, dtype=np.float64).ravel()
+            y = np.ascontiguousarray(b, dtype=np.float64).ravel()
+            fn, ct = getattr(self._L, f64name), C.c_double
+        with self._lock:
+            self._check(fn(self._ctx, _ptr(x, ct), _ptr(y, ct), x.size, C.byref(out)))
+        return out.value
+
+    def cross_correlation_coefficient(self, a, b):
+        return self._pair(a, b, "hh_cross_correlation", "hh_cross_correlation_f64")
+
+    def cosine_similarity(self, a, b):
+        return self._pair(a, b, "hh_cosine_similarity", "hh_cosine_similarity_f64")
+
+    # -- profiling --------------------------------------------------------------------------
+    def profile(self, enable: bool):
+        with self._lock:
+            self._check(self._L.hh_profile_enable(self._ctx, 1 if enable else 0))
+            self._check(self._L.hh_profile_reset(self._ctx))
+
+    def profile_get(self) -> dict:
+        p = _lib.hh_profile()
+        with self._lock:
+            self._check(self._L.hh_profile_get(self._ctx, C.byref(p)))
+        return {name: getattr(p, name) for name, _ in p._fields_}
+
+    def algorithmic_bytes(self) -> int:
+        return int(self._L.hh_algorithmic_bytes(self.n))
+
+
+# ------------------------------------------------------------------------------------------
+# module-level engines, one per (side, device)
+# ------------------------------------------------------------------------------------------
+_engines: dict = {}
+_engines_lock = threading.Lock()
+
+
+def _engine(n: int, device: int = 0) -> SweepEngine:
+    with _engines_lock:
+        e = _engines.get((n, device))
+        if e is None:
+            e = _engines[(n, device)] = SweepEngine(n, device)
+        return e
+
+
+def _square_side(ny, nx):
+    if ny != nx or ny not in _SUPPORTED_N:
+        raise ValueError(f"the gfx950 path handles square images with side in {_SUPPORTED_N}; got ({ny}, {nx})")
+    return int(ny)
+
+
+# ------------------------------------------------------------------------------------------
+# drop-in primitives
+# ------------------------------------------------------------------------------------------
+def simulate_helical_projection(n, twist, rise, csym, helical_diameter, ball_radius, polymer, planarity,
+                                ny, nx, apix, tilt=0, rot=0, psi=0, dy=0, *, device=0):
+    """utils.py:31-47.  ``n > 1`` draws the asymmetric unit from the global NumPy RNG exactly as the
+    reference does (utils.py:139-144); the random-polymer branch is not provided."""
+    assert helical_diameter + ball_radius < ny * apix * 0.99  # utils.py:88
+    if polymer:
+        raise NotImplementedError("polymer (random-walk) asymmetric units are outside the accelerated path")
+    assert n >= 1
+    if not rise > 0:
+        raise ValueError("negative dimensions are not allowed")  # what np.zeros raises in the reference
+    side = _square_side(ny, nx)
+    eng = _engine(side, device)
+    units = None
+    rot_dev = float(rot)
+    if n > 1:
+        c0 = np.zeros((n, 3), dtype=np.float32)
+        r = np.sqrt(np.random.uniform(0, helical_diameter**2 / 4, n))
+        angle = np.random.uniform(-np.pi, np.pi, n) + np.deg2rad(rot)
+        c0[:, 0] = r * np.cos(angle)
+        c0[:, 1] = r * np.sin(angle)
+        c0[:, 2] = np.random.uniform(-rise / 2, rise / 2, n)
+        units = units_to_cylindrical(c0)
+        rot_dev = 0.0  # already folded into the drawn azimuths
+    eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
+                     tilt=tilt, psi=psi, dy=dy, units=units)
+    return eng.simulate(twist, rise, int(csym), rot_dev).astype(np.float64)
+
+
+def compute_power_spectra(data, apix, cutoff_res=None, output_size=None, log=True,
+                          low_pass_fraction=0, high_pass_fraction=0, *, device=0):
+    """transforms.py:771-779 for the default Fourier sampling; returns ``(pwr, phase)``."""
+    data = np.asarray(data)
+    if data.ndim != 2:
+        raise NotImplementedError("only 2D images are on the accelerated path")
+    if cutoff_res is not None and tuple(cutoff_res) != (2 * apix, 2 * apix):
+        raise NotImplementedError("Fourier-space zoom (cutoff_res) is outside the accelerated path")
+    if output_size is not None and tuple(output_size) != tuple(data.shape):
+        raise NotImplementedError("Fourier-space zoom (output_size) is outside the accelerated path")
+    if 0 < low_pass_fraction < 1 or 0 < high_pass_fraction < 1:
+        raise NotImplementedError("low/high-pass filtering of the spectrum is outside the accelerated path")
+    side = _square_side(*data.shape)
+    pwr, phase = _engine(side, device).power_spectrum(data, log=log, want_phase=True)
+    return pwr.astype(np.float64), phase.astype(np.float64)
+
+
+def cross_correlation_coefficient(a, b, *, device=0):
+    """analysis.py:777-799."""
+    return _engine(64, device).cross_correlation_coefficient(a, b)
+
+
+def cosine_similarity(a, b, *, device=0):
+    """analysis.py:802-821."""
+    return _engine(64, device).cosine_similarity(a, b)
+
+
+# ------------------------------------------------------------------------------------------
+# the sweep
+# ------------------------------------------------------------------------------------------
+@dataclass
+class SweepResult:
+    scores: np.ndarray      # [S, C, T, R] float32; skipped candidates are -inf
+    grid: CandidateGrid
+    best_index: np.ndarray  # [S] flat candidate index of the arg-max (lowest index on ties)
+    best: list              # [S] tuples (twist, rise, csym, score)
+
+
+def _argmax(scores_1d: np.ndarray) -> int:
+    L = _lib.lib()
+    s = _f32(scores_1d)
+    idx = C.c_int64(0)
+    _lib.check(L.hh_argmax(_ptr(s, C.c_float), s.size, C.byref(idx)), None)
+    return int(idx.value)
+
+
+def finish_sweep(scores: np.ndarray, grid: CandidateGrid) -> SweepResult:
+    """scores [S, G] -> SweepResult (mask skipped candidates, arg-max per segment)."""
+    scores = np.array(scores, dtype=np.float32, copy=True)
+    scores[:, ~grid.valid] = -np.inf
+    best_index = np.array([_argmax(s) for s in scores], dtype=np.int64)
+    best = []
+    for s, g in enumerate(best_index):
+        tw, rs, cs, _ = grid.params[g]
+        best.append((float(tw), float(rs), int(cs), float(scores[s, g])))
+    return SweepResult(scores.reshape((scores.shape[0],) + grid.shape), grid, best_index, best)
+
+
+def sweep(images, twists, rises, csyms=(1,), *, apix, helical_diameter, ball_radius, mask=None, log=True,
+          rot=0.0, tilt=0.0, psi=0.0, dy=0.0, device=0, engine: SweepEngine | None = None) -> SweepResult:
+    """Score every (csym, twist, rise) candidate against the experimental image(s) on one GPU.
+    For several GPUs see ``helicon_amd.distributed.sweep_distributed``."""
+    imgs = np.asarray(images)
+    side = _square_side(*imgs.shape[-2:])
+    eng = engine or _engine(side, device)
+    grid = build_grid(twists, rises, csyms, tube_length=side * apix, rot=rot)
+    eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
+                     tilt=tilt, psi=psi, dy=dy)
+    eng.set_reference(imgs, mask, log=log)
+    params = grid.params.copy()
+    params[~grid.valid, 1] = 1.0  # skipped pairs still occupy a slot; give them a harmless rise
+    return finish_sweep(eng.sweep(params), grid)
+
+
+# ------------------------------------------------------------------------------------------
+# pipeline.process_one_task tuple layout (pipeline.py:85-122, 469-497), Path-B scoring
+# ------------------------------------------------------------------------------------------
+def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range,
+                     psi, psi_range, dy, dy_range, apix2d_orig, denoise, low_pass, transpose, horizontalize,
+                     target_apix3d, target_apix2d, thresh_fraction, positive_constraint, tube_length,
+                     tube_diameter, tube_diameter_inner, reconstruct_length, sym_oversample, interpolation,
+                     fsc_test, return_3d, score_metric, algorithm, verbose, n_cpu=1):
+    """Same positional signature and return layout as the reference task function, scored by the
+    Fourier layer-line correlation instead of the sparse least-squares reconstruction:
+    ``None`` for a blank image (pipeline.py:214-218), else
+    ``(score, (None, None, None, None, D2d, D3d, L2d, L3d), (data, imageFile, imageIndex, apix3d,
+    apix2d, twist, rise, csym, tilt, psi, dy))``.  ``algorithm`` may carry ``helical_diameter``,
+    ``ball_radius``, ``mask`` and ``log``; image preparation options of the reference that need
+    scikit-image (denoise, horizontalize, rescaling) are rejected."""
+    if data is None:
+        raise NotImplementedError("reading images from disk (mrcfile) is outside the accelerated path")
+    data = np.asarray(data)
+    if np.std(data) == 0:
+        return None
+    if denoise or (low_pass is not None and low_pass > 0) or horizontalize:
+        raise NotImplementedError("denoise / low_pass / horizontalize are outside the accelerated path")
+    if target_apix2d is not None and target_apix2d > 0 and abs(target_apix2d - apix2d_orig) > 1e-6:
+        raise NotImplementedError("rescaling to target_apix2d is outside the accelerated path")
+    if transpose:
+        data = data.T
+    ny, nx = data.shape
+    side = _square_side(ny, nx)
+    apix = float(apix2d_orig)
+    opts = dict(algorithm or {})
+    diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))
+    ball_radius = float(opts.get("ball_radius", 2.0 * apix))
+    eng = _engine(side, int(opts.get("device", 0)))
+    eng.set_geometry(apix=apix, helical_diameter=diameter, ball_radius=ball_radius, tilt=tilt, psi=psi, dy=dy)
+    eng.set_reference(data, opts.get("mask"), log=bool(opts.get("log", True)))
+    score = float(eng.sweep(np.array([[twist, rise, csym, 0.0]]))[0, 0])
+    apix3d = target_apix3d if (target_apix3d is not None and target_apix3d > 0) else apix
+    return (
+        score,
+        (None, None, None, None, nx, ny, nx, nx),
+        (data, imageFile, imageIndex, apix3d, apix, twist, rise, csym, tilt, psi, dy),
+    )

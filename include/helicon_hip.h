@@ -1,0 +1,138 @@
+/*
+ * helicon_hip.h — C ABI of libhelicon_hip.so: the MI355X (gfx950) implementation of the
+ * denovo3D / HILL-style (twist, rise, Csym) sweep ("Path B" of SURVEY.md).
+ *
+ * The reference (jianglab/helicon) is pure Python and has no FFI for this path; what a
+ * maintainer would bind is the three primitives the sweep composes and the thread-pool loop
+ * that drives them.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference's src/helicon/):
+ *
+ *   hh_simulate            webApps/denovo3D/utils.py:31-189   simulate_helical_projection
+ *   hh_power_spectrum      lib/transforms.py:771-820          compute_power_spectra (defaults)
+ *   hh_cross_correlation   lib/analysis.py:777-799            cross_correlation_coefficient
+ *   hh_cosine_similarity   lib/analysis.py:802-821            cosine_similarity
+ *   hh_set_reference +     webApps/denovo3D/app.py:2455-2523  reconstruction_task (the pool over
+ *   hh_sweep[_device]                                         candidates) scoring each candidate by
+ *                                                             cc(ref[mask], pwr[mask])
+ *                                                             (lib/alignment.py:144-147 idiom)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * negative hh_status otherwise, with a message available from hh_last_error(); nothing calls
+ * exit(); no host pointer is retained after a call returns.  Images are square, side N a power
+ * of two in [32, 1024], C-order float32 with the helical axis along the columns (x).
+ * A context is bound to one device and is NOT thread-safe (serialise calls per context).
+ */
+#ifndef HELICON_HIP_H
+#define HELICON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HH_ABI_VERSION 1
+#define HH_MAX_UNITS 64
+
+typedef enum hh_status {
+  HH_OK = 0,
+  HH_ERR_ARG = -1,     /* invalid argument / unsupported size                      */
+  HH_ERR_HIP = -2,     /* a HIP runtime call failed                                */
+  HH_ERR_STATE = -3,   /* call order (e.g. sweep before set_reference/geometry)    */
+  HH_ERR_NOMEM = -4    /* host or device allocation failed                         */
+} hh_status;
+
+typedef struct hh_ctx hh_ctx;
+
+/* Lattice geometry shared by all candidates of a sweep: the scalar arguments of
+ * simulate_helical_projection (utils.py:31-47) other than (twist, rise, csym, rot). */
+typedef struct hh_geom {
+  double apix;             /* Angstrom / pixel                                             */
+  double helical_diameter; /* Angstrom; with n_units == 0 one unit sits at radius d/2      */
+  double ball_radius;      /* Angstrom; sigma^2 = ball_radius^2 / ln 2 (utils.py:92)       */
+  double tilt;             /* degrees, out-of-plane tilt   (utils.py:166-168)              */
+  double psi;              /* degrees, in-plane rotation; applied as -psi like utils.py:167 */
+  double dy;               /* Angstrom, shift along the image rows (utils.py:169-170)      */
+  int32_t n_units;         /* 0 or 1: the deterministic single-unit branch (utils.py:145-151);
+                              >1: units[] gives the asymmetric unit explicitly              */
+  int32_t tail_bits;       /* Gaussian support is truncated where a term < 2^-tail_bits
+                              (0 selects the default, 24)                                   */
+  const float* units;      /* host, n_units x 3: (radius A, azimuth deg, axial offset A);
+                              may be NULL when n_units <= 1                                 */
+} hh_geom;
+
+/* Per-kernel device time of the calls since the last hh_profile_reset (HIP events recorded
+ * on the context's stream around every launch while profiling is enabled). */
+typedef struct hh_profile {
+  double ms_first_pass;    /* raster + column FFT kernel                               */
+  double ms_second_pass;   /* row FFT + |F| + log1p + masked moment reduction kernel   */
+  double ms_finalize;      /* Pearson from moments                                     */
+  int64_t n_first_pass;    /* launches                                                 */
+  int64_t n_second_pass;
+  int64_t n_finalize;
+  int64_t candidates;      /* candidates scored                                        */
+} hh_profile;
+
+int hh_abi_version(void);
+int hh_device_count(int* count);
+
+/* device: HIP ordinal; n: image side; max_batch: candidates per launch (0 = default). */
+int hh_create(hh_ctx** out, int device, int n, int max_batch);
+void hh_destroy(hh_ctx* ctx);
+/* candidates per kernel launch this context was created with (the resolved default). */
+int hh_max_batch(const hh_ctx* ctx);
+/* ctx may be NULL: returns the message of the last failed hh_create on this thread. */
+const char* hh_last_error(const hh_ctx* ctx);
+
+/* Run all later work of this context on `hip_stream` (a hipStream_t, e.g. torch's current
+ * stream handle); NULL selects the context's own stream. */
+int hh_set_stream(hh_ctx* ctx, void* hip_stream);
+
+int hh_set_geometry(hh_ctx* ctx, const hh_geom* geom);
+
+/* Experimental image(s) and mask.  images: host, S x N x N float32; mask: host, N x N bytes on
+ * the fftshifted plane (DC at [N/2][N/2]), non-zero = bin takes part in the correlation;
+ * log_flag selects log1p(|F|) (transforms.py:807-810).  The library transforms the images on
+ * the device and keeps, per segment, the Hermitian half-plane weights and the centred
+ * reference spectrum. */
+int hh_set_reference(hh_ctx* ctx, const float* images, int n_segments, const uint8_t* mask, int log_flag);
+
+/* Score G candidates.  params: G x 4 float64 (twist deg, rise A, csym, rot deg), csym-major /
+ * twist / rise order is the caller's business; scores: S x G float32.  A candidate whose
+ * spectrum has zero variance under the mask scores 0 (analysis.py:796-797).
+ * hh_sweep takes host pointers and returns after the scores are on the host;
+ * hh_sweep_device takes device pointers, enqueues on the context's stream and returns. */
+int hh_sweep(hh_ctx* ctx, const double* params, int64_t n_candidates, float* scores);
+int hh_sweep_device(hh_ctx* ctx, const double* d_params, int64_t n_candidates, float* d_scores);
+
+/* arg-max with ties resolved to the lowest index (np.argmax); NaN never wins. */
+int hh_argmax(const float* scores, int64_t n, int64_t* index);
+
+/* One simulated projection (host, N x N float32) for params[4] = (twist, rise, csym, rot). */
+int hh_simulate(hh_ctx* ctx, const double* params, float* image_out);
+
+/* Amplitude spectrum of one host image: pwr_out (N x N, fftshifted, min-max normalised as
+ * transforms.py:817) and phase_out (N x N, radians; may be NULL). */
+int hh_power_spectrum(hh_ctx* ctx, const float* image, int log_flag, float* pwr_out, float* phase_out);
+
+/* Pearson / cosine of two host vectors (float32 or float64), reduced on the device in float64
+ * with the reference's two-pass (means, then centred sums) order of operations. */
+int hh_cross_correlation(hh_ctx* ctx, const float* a, const float* b, int64_t n, double* out);
+int hh_cosine_similarity(hh_ctx* ctx, const float* a, const float* b, int64_t n, double* out);
+int hh_cross_correlation_f64(hh_ctx* ctx, const double* a, const double* b, int64_t n, double* out);
+int hh_cosine_similarity_f64(hh_ctx* ctx, const double* a, const double* b, int64_t n, double* out);
+
+int hh_synchronize(hh_ctx* ctx);
+
+int hh_profile_enable(hh_ctx* ctx, int on);
+int hh_profile_reset(hh_ctx* ctx);
+int hh_profile_get(hh_ctx* ctx, hh_profile* out);
+
+/* Algorithmic HBM bytes per candidate, B_alg(N) = 4 N^2 + 16 N (N/2 + 1). */
+int64_t hh_algorithmic_bytes(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELICON_HIP_H */

@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Tolerances (fp32 kernels vs the float64 reference path):
+  * simulated image      : 5e-6 absolute on O(1) pixel values (Gaussian terms below 2^-24 are dropped)
+  * normalised spectrum  : 2e-5 absolute on values in [0, 1]
+  * correlation scores   : 2e-4 absolute (observed ~1e-5), arg-max identical
+  * vector CC / cosine   : 1e-12 (float64 accumulation on the device)
+"""
+import numpy as np
+import pytest
+
+import helicon_amd as H
+from oracle import path_b as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 2e-4
+
+
+def _noisy_helix(n, apix, tw, rs, cs, seed=0, sigma=0.5):
+    d, br = 0.4 * n * apix, 2 * apix
+    clean = O.simulate_helical_projection(1, tw, rs, cs, d, br, 0, 0, n, n, apix)
+    img = (clean + np.random.default_rng(seed).normal(0, sigma * clean.std(), clean.shape)).astype(np.float32)
+    return img, d, br
+
+
+# ---------------------------------------------------------------------------- B1 simulate
+def test_simulate_matches_golden_vectors(golden_dir):
+    g = np.load(golden_dir / "g1_simulate.npz")
+    checked = 0
+    for k in range(int(g["n_cases"][0])):
+        n, tw, rs, cs, d, br, ny, nx, apix, tilt, rot, psi, dy = g[f"case{k}_args"]
+        if ny != nx:
+            with pytest.raises(ValueError):
+                H.simulate_helical_projection(int(n), tw, rs, int(cs), d, br, 0, 0, int(ny), int(nx), apix)
+            continue
+        out = H.simulate_helical_projection(int(n), tw, rs, int(cs), d, br, 0, 0, int(ny), int(nx), apix,
+                                            tilt=tilt, rot=rot, psi=psi, dy=dy)
+        assert out.shape == (int(ny), int(nx)) and out.dtype == np.float64
+        np.testing.assert_allclose(out, g[f"case{k}_out"], rtol=0, atol=5e-6, err_msg=f"case {k}")
+        checked += 1
+    assert checked >= 8
+
+
+def test_simulate_seeded_multi_unit_branch(golden_dir):
+    g = np.load(golden_dir / "g1_simulate.npz")
+    for k in range(2):
+        tilt, psi, dy = g[f"multi{k}_kw"]
+        np.random.seed(int(g[f"multi{k}_seed"][0]))
+        out = H.simulate_helical_projection(10, 30, 5, 1, 40, 3, 0, 0, 32, 32, 2.0, tilt=tilt, psi=psi, dy=dy)
+        np.testing.assert_allclose(out, g[f"multi{k}_out"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,apix,tw,rs,cs,rot", [(128, 2.0, 29.0, 10.0, 1, 0.0), (256, 1.5, -3.1, 4.9, 2, 77.0),
+                                                 (512, 1.0, 1.2, 4.75, 1, 0.0), (1024, 1.0, 2.4, 9.5, 3, 10.0)])
+def test_simulate_larger_sizes(n, apix, tw, rs, cs, rot):
+    d, br = 0.4 * n * apix, 2 * apix
+    out = H.simulate_helical_projection(1, tw, rs, cs, d, br, 0, 0, n, n, apix, rot=rot)
+    if n <= 256:
+        ref = O.simulate_helical_projection(1, tw, rs, cs, d, br, 0, 0, n, n, apix, rot=rot)
+    else:  # oracle cost is M*N^2 exp: check a band of rows through the helix instead of the full frame
+        centers = O.helical_unit_centers(tw, rs, cs, d, n * apix, rot=rot)
+        rows = np.arange(n // 2 - 8, n // 2 + 8)
+        Y = ((rows.astype(np.float32) - n // 2) * apix)[:, None]
+        X = ((np.arange(n, dtype=np.float32) - n // 2) * apix)[None, :]
+        ref = np.zeros((len(rows), n))
+        s2 = br * br / np.log(2)
+        for yc, xc in centers:
+            ref += np.exp(-((X - xc) ** 2 + (Y - yc) ** 2) / s2)
+        out = out[rows]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=5e-6)
+
+
+def test_simulate_reference_error_behaviour():
+    with pytest.raises(AssertionError):  # utils.py:88
+        H.simulate_helical_projection(1, 30, 5, 1, 64, 3, 0, 0, 32, 32, 2.0)
+    with pytest.raises(NotImplementedError):
+        H.simulate_helical_projection(10, 30, 5, 1, 40, 3, 1, 0.9, 32, 32, 2.0)
+
+
+# ---------------------------------------------------------------------------- B2 spectrum
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("log", [True, False])
+def test_power_spectrum_matches_oracle(n, log):
+    rng = np.random.default_rng(n)
+    img = rng.normal(size=(n, n)).astype(np.float32)
+    pwr, phase = H.compute_power_spectra(img, 2.0, log=log)
+    rp, rph = O.compute_power_spectra(img.astype(np.float64), 2.0, log=log)
+    assert pwr.shape == (n, n) and phase.shape == (n, n)
+    np.testing.assert_allclose(pwr, rp, rtol=0, atol=2e-5)
+    assert pwr.min() == 0.0 and pwr.max() == pytest.approx(1.0, abs=1e-6)
+    # phases where the amplitude is well above rounding; compare on the circle
+    amp = np.abs(np.fft.fftshift(np.fft.fft2(img.astype(np.float64))))
+    sel = amp > 1e-2 * amp.max()
+    dphi = np.angle(np.exp(1j * (phase - rph)))
+    assert np.abs(dphi[sel]).max() < 1e-3
+
+
+def test_power_spectrum_of_structured_image_and_unsupported_options():
+    img, _, _ = _noisy_helix(128, 2.0, 29.0, 10.0, 1, sigma=0.0)
+    pwr, _ = H.compute_power_spectra(img, 2.0)
+    rp, _ = O.compute_power_spectra(img.astype(np.float64), 2.0)
+    np.testing.assert_allclose(pwr, rp, rtol=0, atol=2e-5)
+    with pytest.raises(NotImplementedError):
+        H.compute_power_spectra(img, 2.0, cutoff_res=(8.0, 8.0))
+    with pytest.raises(NotImplementedError):
+        H.compute_power_spectra(img, 2.0, low_pass_fraction=0.5)
+    with pytest.raises(ValueError):
+        H.compute_power_spectra(np.zeros((48, 96), np.float32), 2.0)
+
+
+# ---------------------------------------------------------------------------- B3 scores
+def test_cc_and_cosine_known_answers_and_golden(golden_dir):
+    a = np.array([1, 2, 3])
+    assert abs(H.cross_correlation_coefficient(a, np.array([1, 2, 3])) - 1.0) < 1e-7
+    assert abs(H.cross_correlation_coefficient(a, np.array([3, 2, 1])) + 1.0) < 1e-7
+    assert abs(H.cross_correlation_coefficient(a, np.array([1, 1, 1])) - 0.0) < 1e-7
+    assert abs(H.cosine_similarity(a, np.array([1, 2, 3])) - 1.0) < 1e-7
+    assert abs(H.cosine_similarity(a, np.array([-1, -2, -3])) + 1.0) < 1e-7
+    assert abs(H.cosine_similarity(a, np.array([3, -1, -1 / 3])) - 0) < 1e-7
+    g = np.load(golden_dir / "g2_scores.npz")
+    for n in (3, 1000, 65536):
+        if n <= 1000:
+            x, y = g[f"n{n}_a"], g[f"n{n}_b"]
+        else:
+            rng = np.random.default_rng(n)
+            x = rng.normal(size=n)
+            y = (0.3 * x + rng.normal(size=n)).astype(np.float32)
+            x = x.astype(np.float32)
+        assert H.cross_correlation_coefficient(x, y) == pytest.approx(float(g[f"n{n}_cc"][0]), abs=1e-12)
+        assert H.cosine_similarity(x, y) == pytest.approx(float(g[f"n{n}_cos"][0]), abs=1e-12)
+        x64, y64 = x.astype(np.float64) * (1 + 1e-9), y.astype(np.float64)
+        assert H.cross_correlation_coefficient(x64, y64) == pytest.approx(O.cross_correlation_coefficient(x64, y64), abs=1e-12)
+    ramp = np.arange(17, dtype=np.float64)
+    assert H.cross_correlation_coefficient(ramp, np.full(17, 2.5)) == 0
+    assert H.cosine_similarity(ramp, np.zeros(17)) == 0
+    # the masked idiom of lib/alignment.py:144-147 on 2-D inputs
+    rng = np.random.default_rng(5)
+    p, q = rng.random((64, 64)), rng.random((64, 64))
+    m = H.radial_band_mask(64, 64)
+    assert H.cross_correlation_coefficient(p[m], q[m]) == pytest.approx(O.cross_correlation_coefficient(p[m], q[m]), abs=1e-12)
+
+
+# ---------------------------------------------------------------------------- composition
+@pytest.mark.parametrize("tag", ["n64_c1", "n128_c1", "n64_c3"])
+@pytest.mark.parametrize("log", [True, False])
+def test_sweep_matches_golden_scores_and_argmax(golden_dir, tag, log):
+    g = np.load(golden_dir / "g3_composed.npz")
+    n, apix, tw0, rs0, cs0, d, br = g[f"{tag}_meta"]
+    res = H.sweep(g[f"{tag}_image"], g[f"{tag}_twists"], g[f"{tag}_rises"], (int(cs0),), apix=apix,
+                  helical_diameter=d, ball_radius=br, log=log)
+    ref = g[f"{tag}_scores_log{int(log)}"]
+    got = res.scores[0, 0]
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=SCORE_TOL)
+    assert tuple(np.unravel_index(int(res.best_index[0]), ref.shape)) == tuple(g[f"{tag}_argmax_log{int(log)}"])
+    if log:
+        assert res.best[0][:3] == (tw0, rs0, int(cs0))
+
+
+@pytest.mark.parametrize("n,apix,truth,kw", [
+    (128, 2.0, (29.0, 10.0, 1), dict()),
+    (128, 2.0, (-41.5, 7.3, 2), dict(rot=33.0, dy=3.0)),
+    (256, 1.0, (1.2, 4.75, 1), dict()),
+    (64, 2.0, (65.0, 12.0, 1), dict(tilt=4.0, psi=-3.0, dy=-2.0)),
+])
+def test_sweep_matches_oracle(n, apix, truth, kw):
+    tw0, rs0, cs0 = truth
+    img, d, br = _noisy_helix(n, apix, tw0, rs0, cs0, seed=n)
+    twists = tw0 + np.array([-1.0, -0.3, 0.0, 0.4, 1.1])
+    rises = rs0 + np.array([-0.25, 0.0, 0.15])
+    csyms = (1, 2, 3) if n <= 128 else (1,)
+    rot = kw.pop("rot", 0.0)
+    res = H.sweep(img, twists, rises, csyms, apix=apix, helical_diameter=d, ball_radius=br, rot=rot, **kw)
+    mask = O.radial_band_mask(n, n)
+    ref = O.sweep_cpu(img, res.grid.params[:, :3], mask, apix=apix, helical_diameter=d, ball_radius=br, rot=rot, **kw)
+    np.testing.assert_allclose(res.scores.reshape(-1), ref, rtol=0, atol=SCORE_TOL)
+    assert int(res.best_index[0]) == int(np.argmax(ref))
+
+
+@pytest.mark.parametrize("kind", ["layer", "asymmetric", "tiny"])
+def test_sweep_with_other_masks(kind):
+    n, apix = 64, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1)
+    rng = np.random.default_rng(1)
+    if kind == "layer":
+        mask = H.layer_line_mask(n, n, axial_bins=[6, 13, 19], half_width=1)
+    elif kind == "asymmetric":  # touches the self-conjugate rows/columns, not Friedel symmetric
+        mask = rng.random((n, n)) < 0.3
+    else:
+        mask = np.zeros((n, n), bool)
+        mask[40, 37] = mask[20, 11] = mask[0, 0] = mask[32, 0] = mask[0, 32] = True
+    twists, rises = np.arange(26.0, 32.5, 1.0), np.array([9.0, 10.0, 11.0])
+    res = H.sweep(img, twists, rises, (1,), apix=apix, helical_diameter=d, ball_radius=br, mask=mask)
+    ref = O.sweep_cpu(img, res.grid.params[:, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(res.scores.reshape(-1), ref, rtol=0, atol=5e-4 if kind == "tiny" else SCORE_TOL)
+
+
+def test_sweep_multi_segment_and_skipped_candidates():
+    n, apix = 64, 2.0
+    imgs = []
+    for s, (tw, rs) in enumerate([(29.0, 10.0), (27.0, 9.0), (31.0, 11.0)]):
+        img, d, br = _noisy_helix(n, apix, tw, rs, 1, seed=s)
+        imgs.append(img)
+    imgs = np.stack(imgs)
+    twists = np.array([0.001, 27.0, 29.0, 31.0])   # first twist is skipped by the driver rule
+    rises = np.array([9.0, 10.0, 11.0, 70.0])       # last rise >= tube_length / 2 is skipped
+    res = H.sweep(imgs, twists, rises, (1,), apix=apix, helical_diameter=d, ball_radius=br)
+    assert res.scores.shape == (3, 1, 4, 4)
+    assert np.isneginf(res.scores[:, 0, 0, :]).all() and np.isneginf(res.scores[:, 0, :, 3]).all()
+    mask = O.radial_band_mask(n, n)
+    valid = res.grid.valid
+    for s in range(3):
+        ref = O.sweep_cpu(imgs[s], res.grid.params[valid, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
+        np.testing.assert_allclose(res.scores[s].reshape(-1)[valid], ref, rtol=0, atol=SCORE_TOL)
+    assert [b[:2] for b in res.best] == [(29.0, 10.0), (27.0, 9.0), (31.0, 11.0)]
+
+
+def test_zero_variance_candidate_scores_zero_and_blank_task_is_none():
+    n, apix = 64, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1)
+    with H.SweepEngine(n) as eng:
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        eng.set_reference(img)
+        # rise <= 0: empty lattice -> zero image -> constant spectrum -> 0 (analysis.py:796-797)
+        sc = eng.sweep(np.array([[29.0, -5.0, 1, 0.0], [29.0, 10.0, 1, 0.0]]))
+        assert sc[0, 0] == 0.0 and sc[0, 1] > 0.3
+        assert eng.sweep(np.zeros((0, 4))).shape == (1, 0)
+    args = [0, 1, np.zeros((n, n), np.float32), "f", 0, 29.0, 10.0, 0, 1, 0, 0, 0, 0, 0, 0, apix, "", -1, 0, 0,
+            -1, -1, -1, -1, n * apix, n * apix, 0.0, 30.0, -1, "linear", 0, 0, "cosine", dict(), 0]
+    assert H.process_one_task(*args) is None
+    args[2] = img
+    args[33] = dict(helical_diameter=d, ball_radius=br)
+    out = H.process_one_task(*args)
+    score, ret, meta = out
+    assert len(ret) == 8 and len(meta) == 11 and meta[5:8] == (29.0, 10.0, 1)
+    mask = O.radial_band_mask(n, n)
+    ref = O.sweep_cpu(img, np.array([[29.0, 10.0, 1]]), mask, apix=apix, helical_diameter=d, ball_radius=br)[0]
+    assert score == pytest.approx(ref, abs=SCORE_TOL)
+
+
+def test_call_order_errors():
+    with H.SweepEngine(64) as eng:
+        with pytest.raises(H.HeliconHipError):
+            eng.sweep(np.array([[29.0, 10.0, 1, 0.0]]))
+        eng.set_geometry(apix=2.0, helical_diameter=50.0, ball_radius=4.0)
+        with pytest.raises(H.HeliconHipError):
+            eng.sweep(np.array([[29.0, 10.0, 1, 0.0]]))
+        with pytest.raises(ValueError):
+            eng.set_reference(np.zeros((32, 32), np.float32))
+        with pytest.raises(ValueError):
+            eng.set_reference(np.ones((64, 64), np.float32), mask=np.zeros((64, 64), bool))
+
+
+# ---------------------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize("n,apix,truth", [(512, 1.0, (1.20, 4.75, 1)), (1024, 1.0, (2.4, 9.5, 2))])
+def test_full_size_properties(n, apix, truth):
+    """Size-independent checks at the BASELINE sizes, where the oracle costs seconds per candidate:
+    self-correlation is 1, results do not depend on batching or order, runs are bit-reproducible,
+    and a handful of candidates around the truth agree with the oracle."""
+    tw0, rs0, cs0 = truth
+    d, br = 0.4 * n * apix, 2 * apix
+    with H.SweepEngine(n, max_batch=24) as eng, H.SweepEngine(n, max_batch=7) as eng2:
+        for e in (eng, eng2):
+            e.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        clean = eng.simulate(tw0, rs0, cs0)
+        rng = np.random.default_rng(0)
+        tw = tw0 + 0.01 * rng.integers(-40, 40, 61)
+        rs = rs0 + 0.005 * rng.integers(-40, 40, 61)
+        params = np.stack([tw, rs, np.full(61, cs0), np.zeros(61)], axis=1)
+        params[17] = (tw0, rs0, cs0, 0.0)
+        eng.set_reference(clean)
+        s_clean = eng.sweep(params)[0]
+        assert s_clean[17] == pytest.approx(1.0, abs=2e-5) and int(np.argmax(s_clean)) == 17
+        noisy = (clean + rng.normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
+        eng.set_reference(noisy)
+        eng2.set_reference(noisy)
+        s1 = eng.sweep(params)[0]
+        s2 = eng2.sweep(params)[0]                       # other batch size
+        perm = rng.permutation(61)
+        s3 = eng.sweep(params[perm])[0]                  # other order
+        assert np.array_equal(s1, s2) and np.array_equal(s1[perm], s3) and np.array_equal(s1, eng.sweep(params)[0])
+        assert int(np.argmax(s1)) == 17
+    mask = O.radial_band_mask(n, n)
+    pick = [17, 0, 1] if n == 512 else [17]
+    ref = O.sweep_cpu(noisy, params[pick, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(s1[pick], ref, rtol=0, atol=SCORE_TOL)

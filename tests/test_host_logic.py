@@ -1,0 +1,97 @@
+"""Host-side logic (no GPU): grid construction, masks, sharding, and the library's exports."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import helicon_amd as H
+from helicon_amd import _lib
+from oracle import path_b as O
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_grid_matches_oracle_driver():
+    tw = O.sweep_axis(0.01, 4.00, 0.01)
+    rs = O.sweep_axis(4.000, 5.245, 0.005)
+    np.testing.assert_array_equal(H.sweep_axis(0.01, 4.00, 0.01), tw)
+    np.testing.assert_array_equal(H.sweep_axis(4.000, 5.245, 0.005), rs)
+    g = H.build_grid(tw, rs, (1, 3), tube_length=512.0)
+    p, valid = O.build_candidates(tw, rs, (1, 3), tube_length=512.0)
+    assert g.shape == (2, 400, 250) and len(g) == 200000
+    np.testing.assert_array_equal(g.params[:, :3], p)
+    np.testing.assert_array_equal(g.valid, valid)
+    assert g.unravel(250 * 400 + 251) == (1, 1, 1)
+
+
+def test_grid_filters_and_wrap():
+    g = H.build_grid([0.001, 1.0, 190.0], [0.001, 4.75, 40.0], (1, 2), tube_length=64.0)
+    p, valid = O.build_candidates([0.001, 1.0, 190.0], [0.001, 4.75, 40.0], (1, 2), tube_length=64.0)
+    np.testing.assert_array_equal(g.params[:, :3], p)
+    np.testing.assert_array_equal(g.valid, valid)
+    assert g.params[6, 0] == -170.0
+    for v in (-540.0, -181.0, -180.0, 0.0, 180.0, 180.5, 725.0):
+        assert H.set_to_periodic_range(v) == O.set_to_periodic_range(v)
+    with pytest.raises(ValueError):
+        H.build_grid([1.0], [1.0], (0,), tube_length=10)
+
+
+def test_masks_match_oracle():
+    for n in (32, 64, 512):
+        np.testing.assert_array_equal(H.radial_band_mask(n, n), O.radial_band_mask(n, n))
+    np.testing.assert_array_equal(H.layer_line_mask(64, 64, axial_bins=[3, 9], half_width=1),
+                                  O.layer_line_mask(64, 64, axial_bins=[3, 9], half_width=1))
+    m = H.radial_band_mask(64, 64)
+    assert not m[32, 32] and not m[32, 34] and m[32, 35] and not m[0].any() and not m[:, 0].any()
+
+
+def test_shard_bounds_cover_exactly_once():
+    for n, w in ((100000, 8), (600000, 8), (7, 8), (0, 4), (13, 2), (1000, 1)):
+        seen = np.zeros(n, dtype=int)
+        per = None
+        for r in range(w):
+            lo, hi, per = H.shard_bounds(n, r, w)
+            assert 0 <= lo <= hi <= n and hi - lo <= per
+            seen[lo:hi] += 1
+        assert (seen == 1).all()
+        assert per * w >= n
+
+
+def test_header_symbols_all_exported_and_bound():
+    hdr = (ROOT / "include" / "helicon_hip.h").read_text()
+    declared = set(re.findall(r"^\s*(?:int64_t|int|void|const char\*)\s+(hh_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()  # raises if the .so is missing or lacks a symbol; no GPU call is made
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.hh_abi_version() == 1
+    assert L.hh_algorithmic_bytes(512) == 3153920
+    assert L.hh_algorithmic_bytes(256) == 790528
+    assert L.hh_algorithmic_bytes(1024) == 12599296
+
+
+def test_argmax_rule_is_lowest_index_and_ignores_nan():
+    import ctypes as C
+    L = _lib.lib()
+    s = np.array([np.nan, 0.5, 0.7, 0.7, -np.inf, np.nan], dtype=np.float32)
+    idx = C.c_int64(-1)
+    assert L.hh_argmax(s.ctypes.data_as(C.POINTER(C.c_float)), s.size, C.byref(idx)) == 0
+    assert idx.value == 2
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(H.HeliconHipError):
+        H.SweepEngine(64)
+    with pytest.raises(ValueError):
+        H.SweepEngine(48)
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "helicon_amd").rglob("*.py"):
+        src = f.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, f
