@@ -28,7 +28,7 @@ class hh_geom(C.Structure):
         ("dy", C.c_double),
         ("n_units", C.c_int32),
         ("tail_bits", C.c_int32),
-        ("units", C.POINTER(C.c_float)),
+        ("units", C.POINTER(C.c_double)),
     ]
 
 
@@ -37,9 +37,11 @@ class hh_profile(C.Structure):
         ("ms_first_pass", C.c_double),
         ("ms_second_pass", C.c_double),
         ("ms_finalize", C.c_double),
+        ("ms_centres", C.c_double),
         ("n_first_pass", C.c_int64),
         ("n_second_pass", C.c_int64),
         ("n_finalize", C.c_int64),
+        ("n_centres", C.c_int64),
         ("candidates", C.c_int64),
     ]
 

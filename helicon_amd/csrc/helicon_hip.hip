@@ -175,13 +175,14 @@ __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const float2 (&tw)[TwN
 // ------------------------------------------------------------------------------------------
 struct DevGeom {
   double height;      // nx * apix (utils.py:180)
+  double m[6];        // rows 1 (image row axis) and 2 (helical axis) of R_yx(tilt, -psi)
+  double dy;
   float apix, inv_apix;
   float inv_sigma2;   // ln2 / ball_radius^2
-  float dy;
-  float m[6];         // rows 1 (image row axis) and 2 (helical axis) of R_yx(tilt, -psi)
   int rpx;            // truncation half-window, pixels
   int n_units;
   int has_rot;
+  int cap;            // centres per candidate the centre buffer holds
   int pad_;
 };
 
@@ -206,28 +207,46 @@ __device__ __forceinline__ Cand decode_candidate(const double* __restrict__ p, c
   return c;
 }
 
-// Centre `ci` of the lattice in Angstrom: (row coordinate, axial coordinate) = utils.py:153-171.
-__device__ __forceinline__ void centre_position(const Cand& c, const DevGeom& g, const float* __restrict__ units,
-                                                int ci, float& yc, float& xc) {
+// Centre `ci` of the lattice in Angstrom: (row coordinate, axial coordinate), with the
+// reference's arithmetic types (utils.py:138-171): unit position float32, z-rotation by
+// twist*i + 360 s/csym in float64 then rounded to float32, axial shift added in float32,
+// optional tilt/psi rotation and dy in float64.
+__device__ __forceinline__ float2 centre_position(const Cand& c, const DevGeom& g, const double* __restrict__ units,
+                                                  int ci) {
   const int u = ci % g.n_units;
   const int is = ci / g.n_units;
   const int s = is % c.csym;
   const int i = is / c.csym - c.imax;
-  const float r = units[3 * u], a0 = units[3 * u + 1], z = units[3 * u + 2];
-  double turns = ((double)a0 + c.rot + c.twist * (double)i + (double)s * (360.0 / (double)c.csym)) * (1.0 / 360.0);
-  turns -= floor(turns);
-  float sn, cs;
-  sincospif(2.0f * (float)turns, &sn, &cs);
-  float cu = r * cs, cv = r * sn;
-  float ca = z + (float)((double)i * c.rise);
+  const double r = units[3 * u], az = units[3 * u + 1];
+  const float z = (float)units[3 * u + 2];
+  constexpr double D2R = 0.017453292519943295;
+  double s0, c0;
+  sincos(az + c.rot * D2R, &s0, &c0);
+  const double c0u = (double)(float)(r * c0), c0v = (double)(float)(r * s0);
+  const double theta = (c.twist * (double)i + (double)s * 360.0 / (double)c.csym) * D2R;
+  double st, ct;
+  sincos(theta, &st, &ct);
+  const float cu = (float)(c0u * ct - c0v * st);
+  const float cv = (float)(c0u * st + c0v * ct);
+  const float ca = z + (float)((double)i * c.rise);
+  double yc = cv, xc = ca;
   if (g.has_rot) {
-    const float v2 = g.m[0] * cu + g.m[1] * cv + g.m[2] * ca;
-    const float a2 = g.m[3] * cu + g.m[4] * cv + g.m[5] * ca;
-    cv = v2;
-    ca = a2;
+    yc = g.m[0] * (double)cu + g.m[1] * (double)cv + g.m[2] * (double)ca;
+    xc = g.m[3] * (double)cu + g.m[4] * (double)cv + g.m[5] * (double)ca;
   }
-  yc = cv + g.dy;
-  xc = ca;
+  yc += g.dy;
+  return make_float2((float)yc, (float)xc);
+}
+
+// K_0: one workgroup per candidate writes its lattice centres (float2 {row, axial} in Angstrom);
+// K_A then only streams them.  Candidates with more than `cap` centres are computed on the fly.
+__global__ __launch_bounds__(256) void k_centres(const double* __restrict__ params, const double* __restrict__ units,
+                                                 DevGeom g, float2* __restrict__ centres) {
+  const size_t b = blockIdx.x;
+  const Cand c = decode_candidate(params + 4 * b, g);
+  if (c.M > g.cap) return;
+  float2* const out = centres + b * (size_t)g.cap;
+  for (int ci = threadIdx.x; ci < c.M; ci += blockDim.x) out[ci] = centre_position(c, g, units, ci);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -235,7 +254,8 @@ __device__ __forceinline__ void centre_position(const Cand& c, const DevGeom& g,
 // ------------------------------------------------------------------------------------------
 struct FirstArgs {
   const double* params;   // [B][4] (raster mode)
-  const float* units;     // [n_units][3]
+  const double* units;    // [n_units][3] (radius A, azimuth rad, axial A)
+  const float2* centres;  // [B][cap] from k_centres
   const float* images;    // [B][N][N] (image mode)
   const float2* twtab;    // [N]
   float2* inter;          // [B][N/2][N]
@@ -292,22 +312,23 @@ __global__ __launch_bounds__(KA<N>::THREADS) void k_first_pass(FirstArgs a) {
       const float lo = (float)(xa - g.rpx - 1), hi = (float)(xa + 1 + g.rpx + 1);
       const float qx = (float)(xa + col - N / 2) * g.apix;  // X of utils.py:94-99
       const float fq = (float)(xa + col);
+      const bool stored = c.M <= g.cap;
+      const float2* const cent = a.centres + b * (size_t)g.cap;
       for (int base = 0; base < c.M; base += TL) {
         bool hit = false;
+        float2 p = make_float2(0.f, 0.f);
         const int ci = base + t;
         if (ci < c.M) {
-          float yc, xc;
-          centre_position(c, g, a.units, ci, yc, xc);
-          const float cx = xc * g.inv_apix + (float)(N / 2);
-          const float cy = yc * g.inv_apix + (float)(N / 2);
+          p = stored ? cent[ci] : centre_position(c, g, a.units, ci);
+          const float cx = p.y * g.inv_apix + (float)(N / 2);
+          const float cy = p.x * g.inv_apix + (float)(N / 2);
           hit = (cx >= lo) && (cx <= hi) && (cy >= (float)(-g.rpx - 1)) && (cy <= (float)(N + g.rpx));
         }
         unsigned long long todo = (__ballot(hit) >> gbase) & gmask;
         while (todo) {
           const int k = __ffsll((long long)todo) - 1;
           todo &= todo - 1;
-          float yc, xc;
-          centre_position(c, g, a.units, base + k, yc, xc);
+          const float yc = __shfl(p.x, gbase + k, 64), xc = __shfl(p.y, gbase + k, 64);
           const float cx = xc * g.inv_apix + (float)(N / 2);
           const float cy = yc * g.inv_apix + (float)(N / 2);
           const float dx = qx - xc;
@@ -639,7 +660,9 @@ struct hh_ctx {
   double* d_params = nullptr;    // staging for hh_sweep
   float* d_scores = nullptr;
   int64_t cap_params = 0;
-  float* d_units = nullptr;
+  double* d_units = nullptr;
+  float2* d_centres = nullptr;   // [max_batch][cap]
+  int centre_cap = 4096;
   float2* d_w2 = nullptr;        // [S][N/2+1][N]
   float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
   int64_t cap_spec = 0;
@@ -808,9 +831,16 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
   const int nblk = nblk_for(c->n);
   for (int64_t g0 = 0; g0 < g; g0 += c->max_batch) {
     const int nb = (int)std::min<int64_t>(c->max_batch, g - g0);
+    {
+      ProfScope ps(c, 3);
+      hipLaunchKernelGGL(k_centres, dim3(nb), dim3(256), 0, c->stream, d_params + 4 * g0, c->d_units, c->geom,
+                         c->d_centres);
+    }
+    HH_HIP(c, hipGetLastError());
     FirstArgs fa{};
     fa.params = d_params + 4 * g0;
     fa.units = c->d_units;
+    fa.centres = c->d_centres;
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
     fa.g = c->geom;
@@ -964,7 +994,8 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   HH_CREATE_HIP(hipMalloc(&c->d_tw, (size_t)n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)max_batch * nblk_for(n) * 3 * sizeof(double)));
-  HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(float)));
+  HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMalloc(&c->d_centres, (size_t)max_batch * c->centre_cap * sizeof(float2)));
   std::vector<float2> tw((size_t)n);
   for (int k = 0; k < n; ++k) {
     const double ang = -2.0 * M_PI * (double)k / (double)n;
@@ -990,6 +1021,7 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_params);
   (void)hipFree(c->d_scores);
   (void)hipFree(c->d_units);
+  (void)hipFree(c->d_centres);
   (void)hipFree(c->d_w2);
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
@@ -1030,7 +1062,8 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
   d.inv_apix = (float)(1.0 / g->apix);
   const double sigma2 = g->ball_radius * g->ball_radius / std::log(2.0);
   d.inv_sigma2 = (float)(1.0 / sigma2);
-  d.dy = (float)g->dy;
+  d.dy = g->dy;
+  d.cap = c->centre_cap;
   const int bits = g->tail_bits > 0 ? g->tail_bits : 24;
   // exp(-(R*apix)^2 / sigma2) < 2^-bits
   d.rpx = (int)std::ceil(std::sqrt(sigma2 * bits * std::log(2.0)) / g->apix);
@@ -1041,18 +1074,18 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
     // R = Rx(-psi) * Ry(tilt) (scipy from_euler("yx", (tilt, -psi)), utils.py:167); rows 1, 2
     const double a = g->tilt * M_PI / 180.0, b = -g->psi * M_PI / 180.0;
     const double ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b);
-    d.m[0] = (float)(sb * sa);  d.m[1] = (float)cb;  d.m[2] = (float)(-sb * ca);
-    d.m[3] = (float)(-cb * sa); d.m[4] = (float)sb;  d.m[5] = (float)(cb * ca);
+    d.m[0] = sb * sa;  d.m[1] = cb; d.m[2] = -sb * ca;
+    d.m[3] = -cb * sa; d.m[4] = sb; d.m[5] = cb * ca;
   }
-  std::vector<float> units;
+  std::vector<double> units;
   if (g->n_units <= 1 && !g->units) {
-    units = {(float)(g->helical_diameter / 2.0), 0.f, 0.f};
+    units = {g->helical_diameter / 2.0, 0.0, 0.0};
     d.n_units = 1;
   } else {
     d.n_units = std::max(1, g->n_units);
     units.assign(g->units, g->units + 3 * (size_t)d.n_units);
   }
-  HH_HIP(c, hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HH_HIP(c, hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HH_HIP(c, hipStreamSynchronize(c->stream));
   c->geom = d;
   c->have_geom = true;
@@ -1190,9 +1223,11 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
   HH_HIP(c, hipMalloc(&dp, 4 * sizeof(double)));
   hipError_t e = hipMemcpyAsync(dp, params, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_centres, dim3(1), dim3(256), 0, c->stream, dp, c->d_units, c->geom, c->d_centres);
     FirstArgs fa{};
     fa.params = dp;
     fa.units = c->d_units;
+    fa.centres = c->d_centres;
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
     fa.raster_out = c->d_img;
@@ -1271,6 +1306,7 @@ int hh_profile_get(hh_ctx* c, hh_profile* out) {
     switch (c->events[i].kind) {
       case 0: p.ms_first_pass += ms; p.n_first_pass++; break;
       case 1: p.ms_second_pass += ms; p.n_second_pass++; break;
+      case 3: p.ms_centres += ms; p.n_centres++; break;
       default: p.ms_finalize += ms; p.n_finalize++; break;
     }
   }

@@ -48,13 +48,13 @@ def _ptr(a, ctype):
 
 def units_to_cylindrical(centers_0: np.ndarray) -> np.ndarray:
     """Cartesian asymmetric-unit positions (columns: projection axis, image-row axis, helical axis —
-    the reference's ``centers_0``, utils.py:138-151) -> (radius A, azimuth deg, axial A) float32."""
+    the reference's ``centers_0``, utils.py:138-151) -> (radius A, azimuth rad, axial A) float64."""
     c = np.asarray(centers_0, dtype=np.float64).reshape(-1, 3)
     out = np.empty_like(c)
     out[:, 0] = np.hypot(c[:, 0], c[:, 1])
-    out[:, 1] = np.degrees(np.arctan2(c[:, 1], c[:, 0]))
+    out[:, 1] = np.arctan2(c[:, 1], c[:, 0])
     out[:, 2] = c[:, 2]
-    return out.astype(np.float32)
+    return out
 
 
 class SweepEngine:
@@ -104,7 +104,7 @@ class SweepEngine:
     def set_geometry(self, *, apix, helical_diameter, ball_radius, tilt=0.0, psi=0.0, dy=0.0,
                      units=None, tail_bits=0):
         key = (float(apix), float(helical_diameter), float(ball_radius), float(tilt), float(psi), float(dy),
-               None if units is None else np.asarray(units, dtype=np.float32).tobytes(), int(tail_bits))
+               None if units is None else np.asarray(units, dtype=np.float64).tobytes(), int(tail_bits))
         if key == self._geom_key:
             return
         # the reference asserts (utils.py:88); keep its exception type
@@ -115,9 +115,9 @@ class SweepEngine:
         g.tail_bits = int(tail_bits)
         u = None
         if units is not None:
-            u = _f32(np.asarray(units).reshape(-1, 3))
+            u = np.ascontiguousarray(np.asarray(units, dtype=np.float64).reshape(-1, 3))
             g.n_units = len(u)
-            g.units = _ptr(u, C.c_float)
+            g.units = _ptr(u, C.c_double)
         else:
             g.n_units = 0
             g.units = None
@@ -259,19 +259,14 @@ def simulate_helical_projection(n, twist, rise, csym, helical_diameter, ball_rad
     side = _square_side(ny, nx)
     eng = _engine(side, device)
     units = None
-    rot_dev = float(rot)
-    if n > 1:
-        c0 = np.zeros((n, 3), dtype=np.float32)
+    if n > 1:  # the reference's three draws, in its order (utils.py:140-144); rot is added on the device
         r = np.sqrt(np.random.uniform(0, helical_diameter**2 / 4, n))
-        angle = np.random.uniform(-np.pi, np.pi, n) + np.deg2rad(rot)
-        c0[:, 0] = r * np.cos(angle)
-        c0[:, 1] = r * np.sin(angle)
-        c0[:, 2] = np.random.uniform(-rise / 2, rise / 2, n)
-        units = units_to_cylindrical(c0)
-        rot_dev = 0.0  # already folded into the drawn azimuths
+        angle = np.random.uniform(-np.pi, np.pi, n)
+        z = np.random.uniform(-rise / 2, rise / 2, n)
+        units = np.stack([r, angle, z], axis=1)
     eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
                      tilt=tilt, psi=psi, dy=dy, units=units)
-    return eng.simulate(twist, rise, int(csym), rot_dev).astype(np.float64)
+    return eng.simulate(twist, rise, int(csym), float(rot)).astype(np.float64)
 
 
 def compute_power_spectra(data, apix, cutoff_res=None, output_size=None, log=True,

@@ -58,8 +58,9 @@ typedef struct hh_geom {
                               >1: units[] gives the asymmetric unit explicitly              */
   int32_t tail_bits;       /* Gaussian support is truncated where a term < 2^-tail_bits
                               (0 selects the default, 24)                                   */
-  const float* units;      /* host, n_units x 3: (radius A, azimuth deg, axial offset A);
-                              may be NULL when n_units <= 1                                 */
+  const double* units;     /* host, n_units x 3: (radius A, azimuth rad, axial offset A) — the
+                              reference's r, angle and z draws of utils.py:139-144 before
+                              `rot` is added; may be NULL when n_units <= 1                 */
 } hh_geom;
 
 /* Per-kernel device time of the calls since the last hh_profile_reset (HIP events recorded
@@ -68,9 +69,11 @@ typedef struct hh_profile {
   double ms_first_pass;    /* raster + column FFT kernel                               */
   double ms_second_pass;   /* row FFT + |F| + log1p + masked moment reduction kernel   */
   double ms_finalize;      /* Pearson from moments                                     */
+  double ms_centres;       /* lattice-centre kernel                                    */
   int64_t n_first_pass;    /* launches                                                 */
   int64_t n_second_pass;
   int64_t n_finalize;
+  int64_t n_centres;
   int64_t candidates;      /* candidates scored                                        */
 } hh_profile;
 
