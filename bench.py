@@ -36,11 +36,27 @@ def c2_workload(n=512):
                 twists=twists, rises=rises, build_grid=build_grid)
 
 
+def usable_cores():
+    """Host cores this job may really use: the affinity mask, clipped by the cgroup CPU quota and
+    by the 16-core share a one-GPU box grants (override with HELICON_CPU_CORES)."""
+    env = os.environ.get("HELICON_CPU_CORES")
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline_leg(w, sample_per_core=24):
     """The CPU oracle (NumPy port of the reference path) on this host's cores, bounded sample."""
     from oracle import cpu_baseline
 
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     return cpu_baseline.run(n=w["n"], apix=w["apix"], helical_diameter=w["helical_diameter"],
                             ball_radius=w["ball_radius"], truth=w["truth"], twists=w["twists"], rises=w["rises"],
                             cores=cores, n_candidates=sample_per_core * cores)

@@ -25,6 +25,14 @@
 
 #include "../../include/helicon_hip.h"
 
+// Tuning knobs (compile-time; defaults are the measured best)
+#ifndef HH_KB_PREFETCH
+#define HH_KB_PREFETCH 1   // K_B: load row r+1 while row r is transformed
+#endif
+#ifndef HH_KB_WPS
+#define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -40,6 +48,20 @@ __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.
 // LDS index padding: one extra complex slot every 8 breaks the power-of-two strides of the
 // Stockham scatter (stride 8 / 64 complex) across the 32/64 LDS banks.
 __host__ __device__ constexpr int lds_pad(int a) { return a + (a >> 3); }
+
+// Synchronise the T lanes that own one transform.  Up to 64 lanes live in one wavefront, whose
+// LDS instructions execute in program order, so only the compiler has to be fenced; wider groups
+// (N = 1024: two wavefronts per transform) need the workgroup barrier.
+template <int T>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (T <= 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
 
 template <int R>
 __device__ __forceinline__ void bfly(float2 (&a)[R]);
@@ -116,6 +138,11 @@ __device__ __forceinline__ void load_twiddles(float2 (&tw)[TwN<N>::total], int t
   if constexpr (P::n > 3) load_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::off3>(tw, t, table);
 }
 
+// LDS slot of natural index (t + m*T) relative to lds_pad(t): a compile-time constant, so every
+// exchange addresses LDS as one base VGPR + immediate offsets (no per-slot index registers).
+template <int T>
+__host__ __device__ constexpr int rd_off(int m) { return m * T + ((m * T) >> 3); }
+
 // One Stockham stage.  Lane t owns butterflies j = t + q*T (q < 8/R); butterfly j reads
 // in[j + r*N/R] — always the lane's own register slots v[q + r*(8/R)] — and writes
 // out[(j/NS)*NS*R + (j mod NS) + r*NS].  The last stage's outputs land back in the same slots,
@@ -123,6 +150,8 @@ __device__ __forceinline__ void load_twiddles(float2 (&tw)[TwN<N>::total], int t
 template <int N, int R, int NS, bool LAST, int OFF>
 __device__ __forceinline__ void fft_stage(float2 (&v)[8], const float2* tw, int t, float2* buf) {
   constexpr int T = N / 8, NB = 8 / R;
+  static_assert(NS == 1 || NS % 8 == 0, "padding algebra below needs NS = 1 or a multiple of 8");
+  static_assert(NS != 1 || R == 8, "the first stage is radix 8");
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     float2 a[R];
@@ -140,20 +169,24 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const float2* tw, int 
       const int j = t + q * T;
       const int k = j & (NS - 1);
       const int j0 = (j - k) * R + k;
+      // lds_pad(j0 + r*NS) = lds_pad(j0) + r * (NS + NS/8)   (NS % 8 == 0), = 9 j + r (NS == 1)
+      float2* const w = buf + lds_pad(j0);
+      constexpr int WS = NS == 1 ? 1 : NS + NS / 8;
 #pragma unroll
-      for (int r = 0; r < R; ++r) buf[lds_pad(j0 + r * NS)] = a[r];
+      for (int r = 0; r < R; ++r) w[r * WS] = a[r];
     }
   }
   if constexpr (!LAST) {
-    __syncthreads();
+    group_sync<T>();
+    const float2* const rd = buf + lds_pad(t);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = buf[lds_pad(t + m * T)];
-    __syncthreads();
+    for (int m = 0; m < 8; ++m) v[m] = rd[rd_off<T>(m)];
+    group_sync<T>();
   }
 }
 
 // In: v[m] = x[t + m*T].  Out: v[m] = X[t + m*T], X = forward DFT (exp(-2 pi i nk/N)).
-// Every thread of the workgroup must call it (block-wide barriers inside).
+// All T lanes of the transform must call it (group_sync inside; block-wide for T > 64).
 template <int N>
 __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const float2 (&tw)[TwN<N>::total], int t, float2* buf) {
   using P = Plan<N>;
@@ -299,7 +332,7 @@ __global__ __launch_bounds__(KA<N>::THREADS) void k_first_pass(FirstArgs a) {
     const Cand c = decode_candidate(a.params + 4 * b, g);
 #pragma unroll
     for (int m = 0; m < 9; ++m) buf[t + m * T] = make_float2(0.f, 0.f);
-    __syncthreads();
+    group_sync<T>();
     // One wavefront (or the T lanes of a narrower group) rasterises the group's two columns:
     // scan the lattice TL centres at a time, then add every hit's (2R+1) x 2 footprint.
     constexpr int TL = T < 64 ? T : 64;
@@ -344,15 +377,15 @@ __global__ __launch_bounds__(KA<N>::THREADS) void k_first_pass(FirstArgs a) {
         }
       }
     }
-    __syncthreads();
+    group_sync<T>();
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = buf[lds_pad(t + m * T)];
+    for (int m = 0; m < 8; ++m) v[m] = buf[lds_pad(t) + rd_off<T>(m)];
     if (a.raster_out != nullptr) {
 #pragma unroll
       for (int m = 0; m < 8; ++m)
         *reinterpret_cast<float2*>(a.raster_out + (b * N + (size_t)(t + m * T)) * N + xa) = v[m];
     }
-    __syncthreads();
+    group_sync<T>();
   } else {
     const float* img = a.images + b * (size_t)N * N;
 #pragma unroll
@@ -364,8 +397,8 @@ __global__ __launch_bounds__(KA<N>::THREADS) void k_first_pass(FirstArgs a) {
   // Split Z into the two real columns' spectra: A[k] = (Z[k] + conj Z[N-k]) / 2,
   // B[k] = (Z[k] - conj Z[N-k]) / (2i), k < N/2; ky = 0 and ky = N/2 (both real) share row 0.
 #pragma unroll
-  for (int m = 0; m < 8; ++m) buf[lds_pad(t + m * T)] = v[m];
-  __syncthreads();
+  for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
+  group_sync<T>();
   float4 ab[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -418,16 +451,22 @@ struct KB {
   static constexpr int NBLK = ROWS / RPW;
   static constexpr int BUF = N + N / 8;
   static constexpr size_t LDS = (size_t)GROUPS * BUF * sizeof(float2);
+  static constexpr int WAVES_PER_SIMD = HH_KB_WPS;  // register budget (512 / WPS VGPRs)
   static_assert(ITERS >= 1 && ITERS * GROUPS == RPW, "row tiling");
 };
 
-__device__ __forceinline__ float amp_to_q(float2 f, int log_flag) {
-  const float a = sqrtf(f.x * f.x + f.y * f.y);
-  return log_flag ? log1pf(a) : a;
+// q = log1p(|F|) or |F| (transforms.py:807-810).  v_sqrt_f32 / v_log_f32 are 1-ulp hardware
+// ops; log(1 + a) has an ABSOLUTE error of ~1e-7 for every a >= 0, which is what the masked sums
+// see (q enters them linearly and squared, never divided by).
+template <int LOG>
+__device__ __forceinline__ float amp_to_q(float2 f) {
+  const float a = __builtin_amdgcn_sqrtf(f.x * f.x + f.y * f.y);
+  if constexpr (LOG) return __logf(1.0f + a);
+  return a;
 }
 
-template <int N, int EPI>
-__global__ __launch_bounds__(KB<N>::THREADS) void k_second_pass(SecondArgs a) {
+template <int N, int EPI, int LOG>
+__global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_second_pass(SecondArgs a) {
   using K = KB<N>;
   constexpr int T = K::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -437,57 +476,43 @@ __global__ __launch_bounds__(KB<N>::THREADS) void k_second_pass(SecondArgs a) {
   float2* const buf = bufs + gi * K::BUF;
   const size_t b = blockIdx.y;
   const float2* const in = a.inter + b * (size_t)K::ROWS * N;
+  const int row0 = blockIdx.x * K::RPW + gi;  // this group's rows: row0 + it * GROUPS
 
   float2 tw[TwN<N>::total];
   load_twiddles<N>(tw, t, a.twtab);
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 
+#if HH_KB_PREFETCH
+  float2 nxt[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) nxt[m] = in[(size_t)row0 * N + t + m * T];
+#endif
+
 #pragma unroll 1
   for (int it = 0; it < K::ITERS; ++it) {
-    const int row = blockIdx.x * K::RPW + it * K::GROUPS + gi;
-    const float2* const src = in + (size_t)row * N;
+    const int row = row0 + it * K::GROUPS;
     float2 v[8];
+#if HH_KB_PREFETCH
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = src[t + m * T];
+    for (int m = 0; m < 8; ++m) v[m] = nxt[m];
+    if (it + 1 < K::ITERS) {  // next row's loads fly under this row's butterflies
+      const float2* const src = in + (size_t)(row + K::GROUPS) * N;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) nxt[m] = src[t + m * T];
+    }
+#else
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = in[(size_t)row * N + t + m * T];
+#endif
     fft_lanes<N>(v, tw, t, buf);  // v[m] = C[kx = t + m*T]
 
-    if (blockIdx.x == 0 && it == 0) {
-      // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]).
-      // (workgroup-uniform branch: all groups take the barriers, group 0 uses the result)
-#pragma unroll
-      for (int m = 0; m < 8; ++m) buf[lds_pad(t + m * T)] = v[m];
-      __syncthreads();
-      if (gi == 0) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int kx = t + m * T;
-          const float2 ck = v[m];
-          const float2 cm = buf[lds_pad((N - kx) & (N - 1))];
-          const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
-          const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
-          if constexpr (EPI == EPI_SCORE) {
-            const float2 w0 = a.w2[kx];
-            const float2 wn = a.w2[(size_t)(N / 2) * N + kx];
-            const float q0 = amp_to_q(f0, a.log_flag), qn = amp_to_q(fn, a.log_flag);
-            s1 += w0.x * q0 + wn.x * qn;
-            s2 += w0.x * q0 * q0 + wn.x * qn * qn;
-            s3 += w0.y * q0 + wn.y * qn;
-          } else {
-            float2* const so = a.spec_out + b * (size_t)(N / 2 + 1) * N;
-            so[kx] = f0;
-            so[(size_t)(N / 2) * N + kx] = fn;
-          }
-        }
-      }
-      __syncthreads();
-      if (gi == 0) continue;
-    }
+    if (row == 0) continue;  // the packed row is un-packed after the loop
     if constexpr (EPI == EPI_SCORE) {
       const float2* const wrow = a.w2 + (size_t)row * N;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const float2 w = wrow[t + m * T];
-        const float q = amp_to_q(v[m], a.log_flag);
+        const float q = amp_to_q<LOG>(v[m]);
         s1 += w.x * q;
         s2 += w.x * q * q;
         s3 += w.y * q;
@@ -496,6 +521,41 @@ __global__ __launch_bounds__(KB<N>::THREADS) void k_second_pass(SecondArgs a) {
       float2* const so = a.spec_out + (b * (size_t)(N / 2 + 1) + row) * N;
 #pragma unroll
       for (int m = 0; m < 8; ++m) so[t + m * T] = v[m];
+    }
+  }
+
+  // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]); un-pack it into the
+  // ky = 0 and ky = N/2 rows.  Done once per candidate, outside the row loop, by the first
+  // transform group(s) of workgroup 0 (all lanes of a T > 64 group's workgroup take the barriers).
+  if (blockIdx.x == 0 && (gi == 0 || T > 64)) {
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = in[t + m * T];
+    fft_lanes<N>(v, tw, t, buf);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
+    group_sync<T>();
+    if (gi == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int kx = t + m * T;
+        const float2 ck = v[m];
+        const float2 cm = buf[lds_pad((N - kx) & (N - 1))];
+        const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
+        const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
+        if constexpr (EPI == EPI_SCORE) {
+          const float2 w0 = a.w2[kx];
+          const float2 wn = a.w2[(size_t)(N / 2) * N + kx];
+          const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
+          s1 += w0.x * q0 + wn.x * qn;
+          s2 += w0.x * q0 * q0 + wn.x * qn * qn;
+          s3 += w0.y * q0 + wn.y * qn;
+        } else {
+          float2* const so = a.spec_out + b * (size_t)(N / 2 + 1) * N;
+          so[kx] = f0;
+          so[(size_t)(N / 2) * N + kx] = fn;
+        }
+      }
     }
   }
 
@@ -741,17 +801,17 @@ int launch_first(hh_ctx* c, const FirstArgs& a, int batch) {
   return HH_OK;
 }
 
-template <int N, int EPI>
+template <int N, int EPI, int LOG>
 int launch_second(hh_ctx* c, const SecondArgs& a, int batch) {
   using K = KB<N>;
   static bool attr_done = false;
   if (!attr_done) {
-    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_second_pass<N, EPI>),
+    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_second_pass<N, EPI, LOG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
     attr_done = true;
   }
   ProfScope ps(c, 1);
-  hipLaunchKernelGGL((k_second_pass<N, EPI>), dim3(K::NBLK, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  hipLaunchKernelGGL((k_second_pass<N, EPI, LOG>), dim3(K::NBLK, batch), dim3(K::THREADS), K::LDS, c->stream, a);
   HH_HIP(c, hipGetLastError());
   return HH_OK;
 }
@@ -769,17 +829,23 @@ int dispatch_first(hh_ctx* c, const FirstArgs& a, int batch) {
   return fail(c, HH_ERR_ARG, "unsupported image size");
 }
 
-template <int EPI>
-int dispatch_second(hh_ctx* c, const SecondArgs& a, int batch) {
+template <int EPI, int LOG>
+int dispatch_second_n(hh_ctx* c, const SecondArgs& a, int batch) {
   switch (c->n) {
-    case 32: return launch_second<32, EPI>(c, a, batch);
-    case 64: return launch_second<64, EPI>(c, a, batch);
-    case 128: return launch_second<128, EPI>(c, a, batch);
-    case 256: return launch_second<256, EPI>(c, a, batch);
-    case 512: return launch_second<512, EPI>(c, a, batch);
-    case 1024: return launch_second<1024, EPI>(c, a, batch);
+    case 32: return launch_second<32, EPI, LOG>(c, a, batch);
+    case 64: return launch_second<64, EPI, LOG>(c, a, batch);
+    case 128: return launch_second<128, EPI, LOG>(c, a, batch);
+    case 256: return launch_second<256, EPI, LOG>(c, a, batch);
+    case 512: return launch_second<512, EPI, LOG>(c, a, batch);
+    case 1024: return launch_second<1024, EPI, LOG>(c, a, batch);
   }
   return fail(c, HH_ERR_ARG, "unsupported image size");
+}
+
+template <int EPI>
+int dispatch_second(hh_ctx* c, const SecondArgs& a, int batch) {
+  if (EPI == EPI_SCORE && a.log_flag) return dispatch_second_n<EPI, 1>(c, a, batch);
+  return dispatch_second_n<EPI, 0>(c, a, batch);
 }
 
 int ensure_img(hh_ctx* c, int64_t count) {
