@@ -27,7 +27,13 @@
 
 // Tuning knobs (compile-time; defaults are the measured best)
 #ifndef HH_KB_PREFETCH
-#define HH_KB_PREFETCH 1   // K_B: load row r+1 while row r is transformed
+#define HH_KB_PREFETCH 0   // K_B: load row r+1 while row r is transformed
+#endif
+#ifndef HH_ABLATE
+#define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads
+#endif
+#ifndef HH_KA_WPS
+#define HH_KA_WPS 4        // K_A: waves per SIMD the register allocator must leave room for
 #endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
@@ -143,12 +149,24 @@ __device__ __forceinline__ void load_twiddles(float2 (&tw)[TwN<N>::total], int t
 template <int T>
 __host__ __device__ constexpr int rd_off(int m) { return m * T + ((m * T) >> 3); }
 
+// Where a lane finds its twiddles: its own registers (K_B keeps them across all its rows) or a
+// per-workgroup LDS copy laid out [slot][lane] (K_A, whose raster needs the registers).
+struct TwRegs {
+  const float2* p;
+  __device__ __forceinline__ float2 operator[](int i) const { return p[i]; }
+};
+template <int T>
+struct TwLds {
+  const float2* p;  // already offset by the lane index
+  __device__ __forceinline__ float2 operator[](int i) const { return p[i * T]; }
+};
+
 // One Stockham stage.  Lane t owns butterflies j = t + q*T (q < 8/R); butterfly j reads
 // in[j + r*N/R] — always the lane's own register slots v[q + r*(8/R)] — and writes
 // out[(j/NS)*NS*R + (j mod NS) + r*NS].  The last stage's outputs land back in the same slots,
 // so on return v[m] = X[t + m*T].
-template <int N, int R, int NS, bool LAST, int OFF>
-__device__ __forceinline__ void fft_stage(float2 (&v)[8], const float2* tw, int t, float2* buf) {
+template <int N, int R, int NS, bool LAST, int OFF, typename TW>
+__device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   constexpr int T = N / 8, NB = 8 / R;
   static_assert(NS == 1 || NS % 8 == 0, "padding algebra below needs NS = 1 or a multiple of 8");
   static_assert(NS != 1 || R == 8, "the first stage is radix 8");
@@ -187,8 +205,8 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const float2* tw, int 
 
 // In: v[m] = x[t + m*T].  Out: v[m] = X[t + m*T], X = forward DFT (exp(-2 pi i nk/N)).
 // All T lanes of the transform must call it (group_sync inside; block-wide for T > 64).
-template <int N>
-__device__ __forceinline__ void fft_lanes(float2 (&v)[8], const float2 (&tw)[TwN<N>::total], int t, float2* buf) {
+template <int N, typename TW>
+__device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   using P = Plan<N>;
   fft_stage<N, P::r0, 1, false, 0>(v, tw, t, buf);
   if constexpr (P::n == 2) {
@@ -215,8 +233,9 @@ struct DevGeom {
   int rpx;            // truncation half-window, pixels
   int n_units;
   int has_rot;
-  int cap;            // centres per candidate the centre buffer holds
-  int pad_;
+  int fast;           // 1: the axial coordinate is monotonic in the subunit index (|m[5]| >= 1/4)
+  float slack;        // bound of |axial coordinate - m[5] * i * rise| over the units, Angstrom
+  float pad_;
 };
 
 struct Cand {  // one candidate, decoded once per workgroup
@@ -271,24 +290,13 @@ __device__ __forceinline__ float2 centre_position(const Cand& c, const DevGeom& 
   return make_float2((float)yc, (float)xc);
 }
 
-// K_0: one workgroup per candidate writes its lattice centres (float2 {row, axial} in Angstrom);
-// K_A then only streams them.  Candidates with more than `cap` centres are computed on the fly.
-__global__ __launch_bounds__(256) void k_centres(const double* __restrict__ params, const double* __restrict__ units,
-                                                 DevGeom g, float2* __restrict__ centres) {
-  const size_t b = blockIdx.x;
-  const Cand c = decode_candidate(params + 4 * b, g);
-  if (c.M > g.cap) return;
-  float2* const out = centres + b * (size_t)g.cap;
-  for (int ci = threadIdx.x; ci < c.M; ci += blockDim.x) out[ci] = centre_position(c, g, units, ci);
-}
-
 // ------------------------------------------------------------------------------------------
-// K_A: raster (or image load) + column FFT, 16 image columns per workgroup
+// K_A: raster (or image load) + column FFT.  A workgroup owns a band of image columns of one
+// candidate and walks it in tiles of 16 columns (8 transforms of 2 packed columns each).
 // ------------------------------------------------------------------------------------------
 struct FirstArgs {
   const double* params;   // [B][4] (raster mode)
   const double* units;    // [n_units][3] (radius A, azimuth rad, axial A)
-  const float2* centres;  // [B][cap] from k_centres
   const float* images;    // [B][N][N] (image mode)
   const float2* twtab;    // [N]
   float2* inter;          // [B][N/2][N]
@@ -301,129 +309,224 @@ constexpr int MODE_RASTER = 0, MODE_IMAGE = 1;
 template <int N>
 struct KA {
   static constexpr int T = N / 8;            // lanes per FFT
-  static constexpr int FPW = 8;              // FFTs per workgroup
-  static constexpr int COLS = 2 * FPW;       // image columns per workgroup
+  static constexpr int FPW = 8;              // FFTs per workgroup and tile
+  static constexpr int COLS = 2 * FPW;       // image columns per tile
   static constexpr int THREADS = FPW * T;    // == N
+  static constexpr int NQ = N >= 256 ? N / 128 : 1;      // workgroups per candidate
+  static constexpr int TPW = (N / COLS) / NQ;            // tiles per workgroup
+  static constexpr int BAND = TPW * COLS;                // image columns per workgroup
   static constexpr int BUF = N + N / 8;      // padded complex slots per FFT buffer
   static constexpr int STAGE_ROW = COLS + 2; // complex slots per staging row (+16 B pad)
-  static constexpr size_t LDS = (size_t)FPW * BUF * sizeof(float2);
-  static_assert((size_t)(N / 2) * STAGE_ROW * sizeof(float2) <= LDS, "staging tile must alias the FFT buffers");
+  static constexpr int CL = 1024;            // lattice centres held in LDS at a time
+  static constexpr size_t LDS_FFT = (size_t)FPW * BUF * sizeof(float2);
+  static constexpr size_t LDS_CENT = (size_t)CL * sizeof(float2);
+  static constexpr size_t LDS_TW = (size_t)TwN<N>::total * T * sizeof(float2);  // [slot][lane]
+  static constexpr size_t LDS = LDS_FFT + LDS_CENT + LDS_TW;
+  static_assert((size_t)(N / 2) * STAGE_ROW * sizeof(float2) <= LDS_FFT, "staging tile must alias the FFT buffers");
+  static_assert(TPW * NQ * COLS == N, "column tiling");
 };
 
+// Add to the group's two packed columns every centre of cent[0..count) whose truncated footprint
+// reaches them.  The pixels live in the lanes' FFT input registers: lane t owns rows t + m*T
+// (m < 8) of both columns as v[m].x / v[m].y, so the raster needs no LDS image, no zero fill and
+// no atomics; a centre's 2R+1 rows touch at most two register slots when T = 64.  Centres are
+// visited in lattice order, so every pixel's sum has a fixed order.
+template <int N>
+__device__ __forceinline__ void raster_pair(float2 (&v)[8], const float2* cent, int count, const DevGeom& g, int xa,
+                                            int t, int lane) {
+  constexpr int T = N / 8, TL = T < 64 ? T : 64;
+  const int gbase = T >= 64 ? 0 : lane - t;
+  const unsigned long long gmask = TL == 64 ? ~0ull : ((1ull << TL) - 1ull);
+  const float lo = (float)(xa - g.rpx - 1), hi = (float)(xa + 1 + g.rpx + 1);
+  const float qxa = (float)(xa - N / 2) * g.apix, qxb = (float)(xa + 1 - N / 2) * g.apix;  // X of utils.py:94-99
+  const float rp = (float)g.rpx;
+  for (int base = 0; base < count; base += TL) {
+    bool hit = false;
+    float2 p = make_float2(0.f, 0.f);
+    const int ci = base + (t & (TL - 1));
+    if (ci < count) {
+      p = cent[ci];
+      const float cx = p.y * g.inv_apix + (float)(N / 2);
+      const float cy = p.x * g.inv_apix + (float)(N / 2);
+      hit = (cx >= lo) && (cx <= hi) && (cy >= -rp - 1.f) && (cy <= (float)N + rp);
+    }
+    unsigned long long todo = (__ballot(hit) >> gbase) & gmask;
+    while (todo) {
+      const int k = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      float yc, xc;
+      if constexpr (T >= 64) {  // k is wave-uniform: scalar lane read, no LDS round trip
+        yc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), k));
+        xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), k));
+      } else {
+        yc = __shfl(p.x, gbase + k, 64);
+        xc = __shfl(p.y, gbase + k, 64);
+      }
+      const float cx = xc * g.inv_apix + (float)(N / 2);
+      const float cy = yc * g.inv_apix + (float)(N / 2);
+      const float dxa = qxa - xc, dxb = qxb - xc;
+      const float ea = dxa * dxa, eb = dxb * dxb;
+      const bool cola = fabsf((float)xa - cx) <= rp, colb = fabsf((float)(xa + 1) - cx) <= rp;
+      const int y0 = max(0, (int)ceilf(cy - rp)), y1 = min(N - 1, (int)floorf(cy + rp));
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (m * T > y1 || m * T + T - 1 < y0) continue;  // uniform across the group
+        const int y = t + m * T;
+        if (y >= y0 && y <= y1) {
+          const float dyv = (float)(y - N / 2) * g.apix - yc;
+          const float d2 = dyv * dyv;
+          if (cola) v[m].x += __expf(-(ea + d2) * g.inv_sigma2);
+          if (colb) v[m].y += __expf(-(eb + d2) * g.inv_sigma2);
+        }
+      }
+    }
+  }
+}
+
+// Fill the LDS centre list with centres [first, first + count) of the candidate.
+__device__ __forceinline__ void fill_centres(float2* cent, const Cand& c, const DevGeom& g, const double* units,
+                                          int first, int count, int tid, int nthreads) {
+  for (int i = tid; i < count; i += nthreads) cent[i] = centre_position(c, g, units, first + i);
+}
+
+template <int N, int MODE, bool RESIDENT>
+__device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand& c, int c_lo, int c_hi,
+                                                 const TwLds<N / 8>& tw, float2* bufs, float2* cent) {
+  using K = KA<N>;
+  constexpr int T = K::T;
+  const int tid = threadIdx.x;
+  const int f = tid / T, t = tid % T;
+  float2* const buf = bufs + f * K::BUF;
+  const int band0 = blockIdx.x * K::BAND;
+  const size_t b = blockIdx.y;
+  const DevGeom& g = a.g;
+#pragma unroll 1
+  for (int tile = 0; tile < K::TPW; ++tile) {
+    const int x0 = band0 + tile * K::COLS;
+    const int xa = x0 + 2 * f;
+    float2 v[8];
+    if constexpr (MODE == MODE_RASTER) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
+      // one pass over the LDS centre list; if the band has more candidate centres than the list
+      // holds they are streamed through it in chunks (workgroup-uniform trip count)
+#pragma unroll 1
+      for (int cb = c_lo; cb < c_hi; cb += K::CL) {
+        const int cnt = min(K::CL, c_hi - cb);
+        if constexpr (!RESIDENT) {
+          __syncthreads();
+          fill_centres(cent, c, g, a.units, cb, cnt, tid, K::THREADS);
+          __syncthreads();
+        }
+        if (!(HH_ABLATE & 1)) raster_pair<N>(v, cent, cnt, g, xa, t, tid & 63);
+      }
+      if (a.raster_out != nullptr) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          *reinterpret_cast<float2*>(a.raster_out + (b * N + (size_t)(t + m * T)) * N + xa) = v[m];
+      }
+    } else {
+      const float* img = a.images + b * (size_t)N * N;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = *reinterpret_cast<const float2*>(img + (size_t)(t + m * T) * N + xa);
+    }
+
+    if (!(HH_ABLATE & 2)) fft_lanes<N>(v, tw, t, buf);  // v[m] = Z[t + m*T], Z = DFT_y(col_a + i col_b)
+
+    // Split Z into the two real columns' spectra: A[k] = (Z[k] + conj Z[N-k]) / 2,
+    // B[k] = (Z[k] - conj Z[N-k]) / (2i), k < N/2; ky = 0 and ky = N/2 (both real) share row 0.
+#pragma unroll
+    for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
+    group_sync<T>();
+    float4 ab[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = t + m * T;
+      const float2 zk = v[m];
+      const float2 zm = buf[lds_pad((N - k) & (N - 1))];
+      ab[m] = make_float4(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y), 0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+    }
+    if (t == 0) ab[0] = make_float4(v[0].x, v[4].x, v[0].y, v[4].y);
+    __syncthreads();  // every group is done with its FFT buffer: reuse LDS as the staging tile
+    float2* const stage = bufs;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = t + m * T;
+      *reinterpret_cast<float4*>(stage + k * K::STAGE_ROW + 2 * f) = ab[m];
+    }
+    __syncthreads();
+    float2* const out = a.inter + b * (size_t)(N / 2) * N + x0;
+#pragma unroll
+    for (int p = 0; p < ((HH_ABLATE & 4) ? 1 : 4); ++p) {
+      const int idx = p * K::THREADS + tid;  // (N/2) rows x 8 float4
+      const int row = idx >> 3, c4 = idx & 7;
+      const float4 val = *reinterpret_cast<const float4*>(stage + row * K::STAGE_ROW + 2 * c4);
+      *reinterpret_cast<float4*>(out + (size_t)row * N + 2 * c4) = val;
+    }
+    __syncthreads();  // the staging tile is read out before the next tile's buffers are zeroed
+  }
+}
+
 template <int N, int MODE>
-__global__ __launch_bounds__(KA<N>::THREADS) void k_first_pass(FirstArgs a) {
+__global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_first_pass(FirstArgs a) {
   using K = KA<N>;
   constexpr int T = K::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* const bufs = reinterpret_cast<float2*>(smem);
+  float2* const cent = reinterpret_cast<float2*>(smem + K::LDS_FFT);
   const int tid = threadIdx.x;
   const int f = tid / T, t = tid % T;
   float2* const buf = bufs + f * K::BUF;
-  const int x0 = blockIdx.x * K::COLS;
-  const int xa = x0 + 2 * f;
+  const int band0 = blockIdx.x * K::BAND;
   const size_t b = blockIdx.y;
+  const DevGeom& g = a.g;
 
-  float2 tw[TwN<N>::total];
-  load_twiddles<N>(tw, t, a.twtab);
-  float2 v[8];
-
+  // Lattice centres that can reach this band of columns -> LDS, once per workgroup.  The axial
+  // coordinate of centre (i, s, u) is m5 * i * rise + O(slack), so only a window of subunit
+  // indices i matters; without that monotonicity (steep tilt/psi) every centre is a candidate.
+  Cand c;
+  int c_lo = 0, c_hi = 0;
   if constexpr (MODE == MODE_RASTER) {
-    const DevGeom& g = a.g;
-    const Cand c = decode_candidate(a.params + 4 * b, g);
-#pragma unroll
-    for (int m = 0; m < 9; ++m) buf[t + m * T] = make_float2(0.f, 0.f);
-    group_sync<T>();
-    // One wavefront (or the T lanes of a narrower group) rasterises the group's two columns:
-    // scan the lattice TL centres at a time, then add every hit's (2R+1) x 2 footprint.
-    constexpr int TL = T < 64 ? T : 64;
-    if (t < TL) {
-      float* const zf = reinterpret_cast<float*>(buf);
-      const int lane = tid & 63;
-      const int gbase = lane - (t & 63);
-      const unsigned long long gmask = TL == 64 ? ~0ull : ((1ull << TL) - 1ull);
-      const int col = t & 1;
-      const float lo = (float)(xa - g.rpx - 1), hi = (float)(xa + 1 + g.rpx + 1);
-      const float qx = (float)(xa + col - N / 2) * g.apix;  // X of utils.py:94-99
-      const float fq = (float)(xa + col);
-      const bool stored = c.M <= g.cap;
-      const float2* const cent = a.centres + b * (size_t)g.cap;
-      for (int base = 0; base < c.M; base += TL) {
-        bool hit = false;
-        float2 p = make_float2(0.f, 0.f);
-        const int ci = base + t;
-        if (ci < c.M) {
-          p = stored ? cent[ci] : centre_position(c, g, a.units, ci);
-          const float cx = p.y * g.inv_apix + (float)(N / 2);
-          const float cy = p.x * g.inv_apix + (float)(N / 2);
-          hit = (cx >= lo) && (cx <= hi) && (cy >= (float)(-g.rpx - 1)) && (cy <= (float)(N + g.rpx));
-        }
-        unsigned long long todo = (__ballot(hit) >> gbase) & gmask;
-        while (todo) {
-          const int k = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const float yc = __shfl(p.x, gbase + k, 64), xc = __shfl(p.y, gbase + k, 64);
-          const float cx = xc * g.inv_apix + (float)(N / 2);
-          const float cy = yc * g.inv_apix + (float)(N / 2);
-          const float dx = qx - xc;
-          const bool colok = fabsf(fq - cx) <= (float)g.rpx;
-          const int y0 = (int)ceilf(cy - (float)g.rpx);
-          for (int ro = t >> 1; ro <= 2 * g.rpx; ro += TL / 2) {
-            const int y = y0 + ro;
-            if (colok && y >= 0 && y < N && fabsf((float)y - cy) <= (float)g.rpx) {
-              const float dyv = (float)(y - N / 2) * g.apix - yc;
-              zf[2 * lds_pad(y) + col] += __expf(-(dx * dx + dyv * dyv) * g.inv_sigma2);
-            }
-          }
-        }
-      }
+    c = decode_candidate(a.params + 4 * b, g);
+    c_hi = c.M;
+    if (g.fast && c.M > 0) {
+      const float step = (float)(g.m[5] * c.rise);
+      float i0 = ((float)(band0 - g.rpx - 3 - N / 2) * g.apix - g.slack) / step;
+      float i1 = ((float)(band0 + K::BAND + g.rpx + 3 - N / 2) * g.apix + g.slack) / step;
+      if (i0 > i1) { const float tmp = i0; i0 = i1; i1 = tmp; }
+      i0 = fmaxf(i0, -2.0e9f);
+      i1 = fminf(i1, 2.0e9f);
+      const int ilo = max(-c.imax, (int)floorf(i0) - 1), ihi = min(c.imax, (int)ceilf(i1) + 1);
+      const int per = c.csym * g.n_units;
+      c_lo = (ilo + c.imax) * per;
+      c_hi = ihi < ilo ? c_lo : (ihi + c.imax + 1) * per;
     }
-    group_sync<T>();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = buf[lds_pad(t) + rd_off<T>(m)];
-    if (a.raster_out != nullptr) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-        *reinterpret_cast<float2*>(a.raster_out + (b * N + (size_t)(t + m * T)) * N + xa) = v[m];
+    if (c_hi - c_lo <= K::CL) {
+      fill_centres(cent, c, g, a.units, c_lo, c_hi - c_lo, tid, K::THREADS);
+      __syncthreads();
     }
-    group_sync<T>();
-  } else {
-    const float* img = a.images + b * (size_t)N * N;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = *reinterpret_cast<const float2*>(img + (size_t)(t + m * T) * N + xa);
   }
+  const bool resident = (c_hi - c_lo) <= K::CL;  // workgroup-uniform
 
-  fft_lanes<N>(v, tw, t, buf);  // v[m] = Z[t + m*T], Z = DFT_y(col_a + i col_b)
-
-  // Split Z into the two real columns' spectra: A[k] = (Z[k] + conj Z[N-k]) / 2,
-  // B[k] = (Z[k] - conj Z[N-k]) / (2i), k < N/2; ky = 0 and ky = N/2 (both real) share row 0.
+  // Twiddles: one LDS copy per workgroup, [slot][lane], written by the first transform group.
+  float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_FFT + K::LDS_CENT);
+  if (f == 0) {
+    float2 twr[TwN<N>::total];
+    load_twiddles<N>(twr, t, a.twtab);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
-  group_sync<T>();
-  float4 ab[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int k = t + m * T;
-    const float2 zk = v[m];
-    const float2 zm = buf[lds_pad((N - k) & (N - 1))];
-    ab[m] = make_float4(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y), 0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-  }
-  if (t == 0) ab[0] = make_float4(v[0].x, v[4].x, v[0].y, v[4].y);
-  __syncthreads();  // every group is done with its FFT buffer: reuse LDS as the staging tile
-  float2* const stage = bufs;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int k = t + m * T;
-    *reinterpret_cast<float4*>(stage + k * K::STAGE_ROW + 2 * f) = ab[m];
+    for (int i = 0; i < TwN<N>::total - 1; ++i) twl[i * T + t] = twr[i];
   }
   __syncthreads();
-  float2* const out = a.inter + b * (size_t)(N / 2) * N + x0;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int idx = p * K::THREADS + tid;  // (N/2) rows x 8 float4
-    const int row = idx >> 3, c4 = idx & 7;
-    const float4 val = *reinterpret_cast<const float4*>(stage + row * K::STAGE_ROW + 2 * c4);
-    *reinterpret_cast<float4*>(out + (size_t)row * N + 2 * c4) = val;
-  }
+  const TwLds<T> tw{twl + t};
+
+  // Two copies of the tile loop: the common one never refills the centre list, so the float64
+  // trigonometry of the refill cannot raise its register pressure.
+  if (resident)
+    first_pass_tiles<N, MODE, true>(a, c, c_lo, c_hi, tw, bufs, cent);
+#ifndef HH_NO_CHUNKED
+  else
+    first_pass_tiles<N, MODE, false>(a, c, c_lo, c_hi, tw, bufs, cent);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,7 +607,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = in[(size_t)row * N + t + m * T];
 #endif
-    fft_lanes<N>(v, tw, t, buf);  // v[m] = C[kx = t + m*T]
+    fft_lanes<N>(v, TwRegs{tw}, t, buf);  // v[m] = C[kx = t + m*T]
 
     if (row == 0) continue;  // the packed row is un-packed after the loop
     if constexpr (EPI == EPI_SCORE) {
@@ -531,7 +634,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = in[t + m * T];
-    fft_lanes<N>(v, tw, t, buf);
+    fft_lanes<N>(v, TwRegs{tw}, t, buf);
 #pragma unroll
     for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
     group_sync<T>();
@@ -721,8 +824,6 @@ struct hh_ctx {
   float* d_scores = nullptr;
   int64_t cap_params = 0;
   double* d_units = nullptr;
-  float2* d_centres = nullptr;   // [max_batch][cap]
-  int centre_cap = 4096;
   float2* d_w2 = nullptr;        // [S][N/2+1][N]
   float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
   int64_t cap_spec = 0;
@@ -796,7 +897,7 @@ int launch_first(hh_ctx* c, const FirstArgs& a, int batch) {
     attr_done = true;
   }
   ProfScope ps(c, 0);
-  hipLaunchKernelGGL((k_first_pass<N, MODE>), dim3(N / K::COLS, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  hipLaunchKernelGGL((k_first_pass<N, MODE>), dim3(K::NQ, batch), dim3(K::THREADS), K::LDS, c->stream, a);
   HH_HIP(c, hipGetLastError());
   return HH_OK;
 }
@@ -897,16 +998,9 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
   const int nblk = nblk_for(c->n);
   for (int64_t g0 = 0; g0 < g; g0 += c->max_batch) {
     const int nb = (int)std::min<int64_t>(c->max_batch, g - g0);
-    {
-      ProfScope ps(c, 3);
-      hipLaunchKernelGGL(k_centres, dim3(nb), dim3(256), 0, c->stream, d_params + 4 * g0, c->d_units, c->geom,
-                         c->d_centres);
-    }
-    HH_HIP(c, hipGetLastError());
     FirstArgs fa{};
     fa.params = d_params + 4 * g0;
     fa.units = c->d_units;
-    fa.centres = c->d_centres;
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
     fa.g = c->geom;
@@ -1061,7 +1155,7 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)max_batch * nblk_for(n) * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
-  HH_CREATE_HIP(hipMalloc(&c->d_centres, (size_t)max_batch * c->centre_cap * sizeof(float2)));
+
   std::vector<float2> tw((size_t)n);
   for (int k = 0; k < n; ++k) {
     const double ang = -2.0 * M_PI * (double)k / (double)n;
@@ -1087,7 +1181,6 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_params);
   (void)hipFree(c->d_scores);
   (void)hipFree(c->d_units);
-  (void)hipFree(c->d_centres);
   (void)hipFree(c->d_w2);
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
@@ -1129,7 +1222,6 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
   const double sigma2 = g->ball_radius * g->ball_radius / std::log(2.0);
   d.inv_sigma2 = (float)(1.0 / sigma2);
   d.dy = g->dy;
-  d.cap = c->centre_cap;
   const int bits = g->tail_bits > 0 ? g->tail_bits : 24;
   // exp(-(R*apix)^2 / sigma2) < 2^-bits
   d.rpx = (int)std::ceil(std::sqrt(sigma2 * bits * std::log(2.0)) / g->apix);
@@ -1150,6 +1242,17 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
   } else {
     d.n_units = std::max(1, g->n_units);
     units.assign(g->units, g->units + 3 * (size_t)d.n_units);
+  }
+  {
+    double rmax = 0, zabs = 0;
+    for (int u = 0; u < d.n_units; ++u) {
+      rmax = std::max(rmax, std::fabs(units[3 * u]));
+      zabs = std::max(zabs, std::fabs(units[3 * u + 2]));
+    }
+    const double m3 = d.has_rot ? d.m[3] : 0.0, m4 = d.has_rot ? d.m[4] : 0.0, m5 = d.has_rot ? d.m[5] : 1.0;
+    if (!d.has_rot) { d.m[0] = 0; d.m[1] = 1; d.m[2] = 0; d.m[3] = 0; d.m[4] = 0; d.m[5] = 1; }
+    d.fast = std::fabs(m5) >= 0.25 ? 1 : 0;
+    d.slack = (float)(rmax * (std::fabs(m3) + std::fabs(m4)) + zabs * std::fabs(m5) + 1e-3);
   }
   HH_HIP(c, hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HH_HIP(c, hipStreamSynchronize(c->stream));
@@ -1289,11 +1392,9 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
   HH_HIP(c, hipMalloc(&dp, 4 * sizeof(double)));
   hipError_t e = hipMemcpyAsync(dp, params, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_centres, dim3(1), dim3(256), 0, c->stream, dp, c->d_units, c->geom, c->d_centres);
     FirstArgs fa{};
     fa.params = dp;
     fa.units = c->d_units;
-    fa.centres = c->d_centres;
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
     fa.raster_out = c->d_img;

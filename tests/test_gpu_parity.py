@@ -163,6 +163,8 @@ def test_sweep_matches_golden_scores_and_argmax(golden_dir, tag, log):
     (128, 2.0, (-41.5, 7.3, 2), dict(rot=33.0, dy=3.0)),
     (256, 1.0, (1.2, 4.75, 1), dict()),
     (64, 2.0, (65.0, 12.0, 1), dict(tilt=4.0, psi=-3.0, dy=-2.0)),
+    (64, 2.0, (65.0, 12.0, 1), dict(psi=80.0)),          # axial coordinate not monotonic: full lattice scan
+    (128, 2.0, (29.0, 0.11, 1), dict()),                 # > 1024 candidate centres per band: chunked LDS list
 ])
 def test_sweep_matches_oracle(n, apix, truth, kw):
     tw0, rs0, cs0 = truth
@@ -170,6 +172,8 @@ def test_sweep_matches_oracle(n, apix, truth, kw):
     twists = tw0 + np.array([-1.0, -0.3, 0.0, 0.4, 1.1])
     rises = rs0 + np.array([-0.25, 0.0, 0.15])
     csyms = (1, 2, 3) if n <= 128 else (1,)
+    if rs0 < 1.0:  # dense lattice: keep the oracle affordable
+        twists, rises, csyms = tw0 + np.array([-1.0, 0.0, 0.4]), rs0 + np.array([0.0, 0.02]), (1,)
     rot = kw.pop("rot", 0.0)
     res = H.sweep(img, twists, rises, csyms, apix=apix, helical_diameter=d, ball_radius=br, rot=rot, **kw)
     mask = O.radial_band_mask(n, n)
