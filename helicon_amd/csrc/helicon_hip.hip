@@ -33,7 +33,7 @@
 #define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads
 #endif
 #ifndef HH_KA_WPS
-#define HH_KA_WPS 4        // K_A: waves per SIMD the register allocator must leave room for
+#define HH_KA_WPS 6        // K_A: waves per SIMD the register allocator must leave room for (3 workgroups per CU)
 #endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
@@ -271,13 +271,12 @@ __device__ __forceinline__ float2 centre_position(const Cand& c, const DevGeom& 
   const int i = is / c.csym - c.imax;
   const double r = units[3 * u], az = units[3 * u + 1];
   const float z = (float)units[3 * u + 2];
-  constexpr double D2R = 0.017453292519943295;
+  // angles in half-turns for sincospi (exact argument reduction, no large-argument path)
   double s0, c0;
-  sincos(az + c.rot * D2R, &s0, &c0);
+  sincospi(az * 0.31830988618379067 + c.rot * (1.0 / 180.0), &s0, &c0);
   const double c0u = (double)(float)(r * c0), c0v = (double)(float)(r * s0);
-  const double theta = (c.twist * (double)i + (double)s * 360.0 / (double)c.csym) * D2R;
   double st, ct;
-  sincos(theta, &st, &ct);
+  sincospi((c.twist * (double)i + (double)s * 360.0 / (double)c.csym) * (1.0 / 180.0), &st, &ct);
   const float cu = (float)(c0u * ct - c0v * st);
   const float cv = (float)(c0u * st + c0v * ct);
   const float ca = z + (float)((double)i * c.rise);
@@ -304,7 +303,7 @@ struct FirstArgs {
   DevGeom g;
 };
 
-constexpr int MODE_RASTER = 0, MODE_IMAGE = 1;
+constexpr int MODE_RASTER = 0, MODE_IMAGE = 1, MODE_RASTER_OUT = 2;  // 2: also store the raster image
 
 template <int N>
 struct KA {
@@ -368,15 +367,27 @@ __device__ __forceinline__ void raster_pair(float2 (&v)[8], const float2* cent, 
       const float ea = dxa * dxa, eb = dxb * dxb;
       const bool cola = fabsf((float)xa - cx) <= rp, colb = fabsf((float)(xa + 1) - cx) <= rp;
       const int y0 = max(0, (int)ceilf(cy - rp)), y1 = min(N - 1, (int)floorf(cy + rp));
+      // Walk the footprint's rows in chunks of at most T rows (one chunk for T = 64, R <= 31):
+      // a chunk touches each lane at most once, in register slot m0 or m0 + 1, and m0 is
+      // uniform across the group, so the slot is chosen by multiplying with 0/1 weights.
+      for (int ys = y0; ys <= y1; ys += T) {
+        const int ye = min(y1, ys + T - 1);
+        const int m0 = ys / T;
+        const int ya = t + m0 * T;
+        const bool in_a = ya >= ys;
+        const int y = in_a ? ya : ya + T;
+        const float dyv = (float)(y - N / 2) * g.apix - yc;
+        const float d2 = dyv * dyv;
+        const bool rowok = y <= ye;
+        const float px = (rowok && cola) ? __expf(-(ea + d2) * g.inv_sigma2) : 0.f;
+        const float py = (rowok && colb) ? __expf(-(eb + d2) * g.inv_sigma2) : 0.f;
+        const float ax = in_a ? px : 0.f, ay = in_a ? py : 0.f;
+        const float bx = in_a ? 0.f : px, by = in_a ? 0.f : py;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        if (m * T > y1 || m * T + T - 1 < y0) continue;  // uniform across the group
-        const int y = t + m * T;
-        if (y >= y0 && y <= y1) {
-          const float dyv = (float)(y - N / 2) * g.apix - yc;
-          const float d2 = dyv * dyv;
-          if (cola) v[m].x += __expf(-(ea + d2) * g.inv_sigma2);
-          if (colb) v[m].y += __expf(-(eb + d2) * g.inv_sigma2);
+        for (int m = 0; m < 8; ++m) {
+          const float sa = (m == m0) ? 1.f : 0.f, sb = (m == m0 + 1) ? 1.f : 0.f;
+          v[m].x = fmaf(sa, ax, fmaf(sb, bx, v[m].x));
+          v[m].y = fmaf(sa, ay, fmaf(sb, by, v[m].y));
         }
       }
     }
@@ -405,7 +416,7 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
     const int x0 = band0 + tile * K::COLS;
     const int xa = x0 + 2 * f;
     float2 v[8];
-    if constexpr (MODE == MODE_RASTER) {
+    if constexpr (MODE != MODE_IMAGE) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
       // one pass over the LDS centre list; if the band has more candidate centres than the list
@@ -420,7 +431,7 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
         }
         if (!(HH_ABLATE & 1)) raster_pair<N>(v, cent, cnt, g, xa, t, tid & 63);
       }
-      if (a.raster_out != nullptr) {
+      if constexpr (MODE == MODE_RASTER_OUT) {
 #pragma unroll
         for (int m = 0; m < 8; ++m)
           *reinterpret_cast<float2*>(a.raster_out + (b * N + (size_t)(t + m * T)) * N + xa) = v[m];
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
   // indices i matters; without that monotonicity (steep tilt/psi) every centre is a candidate.
   Cand c;
   int c_lo = 0, c_hi = 0;
-  if constexpr (MODE == MODE_RASTER) {
+  if constexpr (MODE != MODE_IMAGE) {
     c = decode_candidate(a.params + 4 * b, g);
     c_hi = c.M;
     if (g.fast && c.M > 0) {
@@ -1127,9 +1138,10 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(nullptr, HH_ERR_HIP, std::string("hh_create: built for gfx950 only, device is ") + prop.gcnArchName);
   if (max_batch <= 0) {
-    // keep one batch of half spectra (N^2 * 4 B each) around 128 MiB: inside the 256 MiB
-    // Infinity Cache together with the streaming traffic of the two passes
-    max_batch = (int)std::max<int64_t>(16, (128LL << 20) / ((int64_t)n * n * 4));
+    // one batch of half spectra (N^2 * 4 B each) = 256 MiB, the size of the Infinity Cache:
+    // measured best on MI355X (larger batches fall out of the cache, smaller ones leave CUs idle
+    // at the tails of the two kernels)
+    max_batch = (int)std::max<int64_t>(16, (256LL << 20) / ((int64_t)n * n * 4));
     max_batch = std::min(max_batch, 4096);
   }
   if (max_batch > 65535) max_batch = 65535;  // gridDim.y
@@ -1399,7 +1411,7 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
     fa.inter = c->d_inter;
     fa.raster_out = c->d_img;
     fa.g = c->geom;
-    rc = dispatch_first<MODE_RASTER>(c, fa, 1);
+    rc = dispatch_first<MODE_RASTER_OUT>(c, fa, 1);
     if (rc == HH_OK) {
       e = hipMemcpyAsync(image_out, c->d_img, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -1,13 +1,14 @@
 #!/bin/bash
-# usage: tools_variants.sh <steps> lib1.so lib2.so ...   (run on the GPU box; prints one line per variant)
+# usage: tools_variants.sh <steps> "<bench args>" lib1.so lib2.so ...   (run on the GPU box)
 steps=$1; shift
+extra=$1; shift
 for lib in "$@"; do
-  HELICON_HIP_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps $steps --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+  HELICON_HIP_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps $steps --warmup 1 --no-cpu-baseline $extra 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     line=line.strip()
     if not line.startswith('{'): continue
     d=json.loads(line); k=d['roofline']['kernels']
-    print('$lib', 'cand/s=%.0f' % d['value'], 'KA=%.1fus' % k['first_pass']['avg_us'], 'KB=%.1fus' % k['second_pass']['avg_us'], 'truth', d['argmax']['is_truth'])
+    print('$lib', '$extra', 'cand/s=%.0f' % d['value'], 'KA=%.1fus' % k['first_pass']['avg_us'], 'KB=%.1fus' % k['second_pass']['avg_us'], 'batch', d['config']['batch'], 'truth', d['argmax']['is_truth'])
 " || exit 1
 done
