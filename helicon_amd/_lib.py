@@ -74,6 +74,7 @@ EXPORTS = {
     "hh_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "hh_profile_reset": (C.c_int, [_ctx]),
     "hh_profile_get": (C.c_int, [_ctx, C.POINTER(hh_profile)]),
+    "hh_calibrate_traffic": (C.c_int, [_ctx, C.c_int, C.c_int64]),
     "hh_algorithmic_bytes": (C.c_int64, [C.c_int]),
 }
 

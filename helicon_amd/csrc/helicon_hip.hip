@@ -809,6 +809,40 @@ __global__ void k_pair_sums(const T* __restrict__ x, const T* __restrict__ y, in
 }
 
 // ------------------------------------------------------------------------------------------
+// traffic-counter calibration (profiling aid): the sweep's two global access shapes on a known
+// byte count, so rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes for THESE shapes
+// (MI355X_MICROARCH.md, HBM: FETCH_SIZE is only calibrated for 16-B-per-lane streams)
+// ------------------------------------------------------------------------------------------
+// mode 0: K_B's read shape — every wavefront reads 4 KB rows as 8 x (64 lanes x 8 B)
+__global__ __launch_bounds__(256) void k_calib_read(const float2* __restrict__ src, size_t rows, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (size_t r = (size_t)blockIdx.x * 4 + wave; r < rows; r += (size_t)gridDim.x * 4) {
+    const float2* p = src + r * 512 + lane;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float2 x = p[m * 64];
+      acc += x.x + x.y;
+    }
+  }
+  if (acc == 123.456f) sink[0] = acc;  // keeps the loads alive, never true for the zero-filled buffer
+}
+
+// mode 1: K_A's write shape — 128-byte row segments (8 lanes x 16 B) at a 4 KB row pitch
+__global__ __launch_bounds__(512) void k_calib_write(float2* __restrict__ dst, size_t tiles) {
+  // one "tile" = 256 rows x 16 complex (32 KB), the staging tile of k_first_pass<512>
+  for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    float2* const out = dst + (tile / 32) * (size_t)256 * 512 + (tile % 32) * 16;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = p * 512 + threadIdx.x;
+      const int row = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<float4*>(out + (size_t)row * 512 + 2 * c4) = make_float4(1.f, 2.f, 3.f, 4.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_create_error;
@@ -1458,6 +1492,30 @@ int hh_cross_correlation(hh_ctx* c, const float* a, const float* b, int64_t n, d
 int hh_cross_correlation_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return pearson(c, a, b, n, out); }
 int hh_cosine_similarity(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
 int hh_cosine_similarity_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
+
+int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
+  if (!c || bytes <= 0 || (mode != 0 && mode != 1)) return fail(c, HH_ERR_ARG, "hh_calibrate_traffic: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  const size_t unit = (size_t)256 * 512 * sizeof(float2);  // one 512-side half spectrum (1 MiB)
+  const size_t n_units = std::max<size_t>(1, (size_t)bytes / unit);
+  float2* buf = nullptr;
+  float* sink = nullptr;
+  HH_HIP(c, hipMalloc(&buf, n_units * unit));
+  HH_HIP(c, hipMalloc(&sink, sizeof(float)));
+  hipError_t e = hipMemsetAsync(buf, 0, n_units * unit, c->stream);
+  if (e == hipSuccess) {
+    if (mode == 0)
+      hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(256), 0, c->stream, buf, n_units * 256, sink);
+    else
+      hipLaunchKernelGGL(k_calib_write, dim3(2048), dim3(512), 0, c->stream, buf, n_units * 32);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(buf);
+  (void)hipFree(sink);
+  if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_calibrate_traffic: ") + hipGetErrorString(e));
+  return HH_OK;
+}
 
 int hh_profile_enable(hh_ctx* c, int on) {
   if (!c) return HH_ERR_ARG;

@@ -218,6 +218,11 @@ class SweepEngine:
             self._check(self._L.hh_profile_get(self._ctx, C.byref(p)))
         return {name: getattr(p, name) for name, _ in p._fields_}
 
+    def calibrate_traffic(self, mode: int, nbytes: int):
+        """Profiling aid: one launch moving ``nbytes`` with the sweep's read (0) / write (1) shape."""
+        with self._lock:
+            self._check(self._L.hh_calibrate_traffic(self._ctx, int(mode), int(nbytes)))
+
     def algorithmic_bytes(self) -> int:
         return int(self._L.hh_algorithmic_bytes(self.n))
 
