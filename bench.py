@@ -141,6 +141,14 @@ def main():
     prof = eng.profile_get() if not args.no_profile else None
     eng.profile(False)
 
+    # the host-pointer API (params H2D + scores D2H inside the call), reported beside `value`
+    host_api = None
+    if world == 1:
+        eng.sweep(grid.params[:1024])
+        th = time.perf_counter()
+        eng.sweep(grid.params)
+        host_api = g_local / (time.perf_counter() - th)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,6 +186,8 @@ def main():
             "argmax": {"twist": best_pair[0], "rise": best_pair[1], "is_truth": best_pair == (tw0, rs0)},
             "hbm_roofline_frac_wall": value / world * b_alg / HBM_PEAK,
         }
+        if host_api is not None:
+            out["host_api_value"] = host_api  # hh_sweep with host buffers, PCIe-inclusive
         if prof is not None and prof["n_second_pass"] > 0:
             out["roofline"] = roofline(prof, n, b_alg)
         if cpu is not None:
