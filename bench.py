@@ -7,8 +7,8 @@
 
 A step = one pass of the sweep over this rank's 100k-candidate shard with the parameters and the
 experimental spectrum already resident in HBM, followed (N > 1) by the RCCL all-gather of the
-scores.  Weak scaling: every rank owns one full 400 x 250 grid (rank r sweeps it with
-Csym = 1 + r % 6, the C3 workload at N = 6), so the job is 100k x N candidates per step.
+scores.  Weak scaling: every rank owns one full 400 x 250 grid at Csym = 1 (rank r sweeps it at
+azimuthal phase rot = 7.5 r degrees, so all ranks do identical work): 100k x N candidates per step.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --same-device rehearses the N > 1 path on a one-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,11 +95,16 @@ def main():
     import helicon_amd as H
     from helicon_amd.distributed import gather_scores
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     n = w["n"]
     eng = H.SweepEngine(n, device=local_rank, max_batch=args.max_batch)
@@ -107,8 +115,7 @@ def main():
     image = (clean + noise).astype(np.float32)
     eng.set_reference(image, H.radial_band_mask(n, n), log=True)
 
-    csym = 1 + rank % 6
-    grid = w["build_grid"](w["twists"], w["rises"], (csym,), tube_length=n * w["apix"])
+    grid = w["build_grid"](w["twists"], w["rises"], (1,), tube_length=n * w["apix"], rot=7.5 * rank)
     assert grid.valid.all()
     g_local = len(grid)
     stream = torch.cuda.current_stream(dev)
@@ -119,7 +126,8 @@ def main():
     def step():
         eng.sweep_device(d_params.data_ptr(), g_local, d_scores.data_ptr())
         if world > 1:
-            return gather_scores(d_scores, g_local * world, g_local)
+            local = d_scores if args.backend == "nccl" else d_scores.cpu()
+            return gather_scores(local, g_local * world, g_local)
         return d_scores
 
     def fence():
@@ -150,11 +158,11 @@ def main():
         host_api = g_local / (time.perf_counter() - th)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness of what was timed: arg-max of this rank's own grid; rank 0 (csym 1) must find the truth
+    # correctness of what was timed: rank 0's grid (rot = 0) must have its arg-max at the truth
     scores = full.cpu().numpy().reshape(world, g_local)
     best = int(np.argmax(scores[0]))
     _, bt, br_ = np.unravel_index(best, (1, len(w["twists"]), len(w["rises"])))
@@ -179,7 +187,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"C2: {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), "
-                            f"400x250 (twist, rise) grid per GPU, Csym = 1 + rank % 6, radial-band mask, log1p|F|",
+                            f"400x250 (twist, rise) grid per GPU, Csym = 1, rot = 7.5 deg x rank, radial-band mask, log1p|F|",
                 "image": n, "grid_per_gpu": g_local, "candidates_per_step": g_local * world,
                 "batch": eng.max_batch, "parallelism": f"grid-shard x{world} + all-gather(scores)",
             },
