@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--profile-period", type=int, default=16,
+                    help="HIP events around the launches of every k-th batch of the timed sweeps (1 = all)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -140,14 +142,14 @@ def main():
         step()
     fence()
     if not args.no_profile:
-        eng.profile(True)
+        eng.profile(args.profile_period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full = step()
     fence()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_get() if not args.no_profile else None
-    eng.profile(False)
+    eng.profile(0)
 
     # the host-pointer API (params H2D + scores D2H inside the call), reported beside `value`
     host_api = None

@@ -30,7 +30,8 @@
 #define HH_KB_PREFETCH 0   // K_B: load row r+1 while row r is transformed
 #endif
 #ifndef HH_ABLATE
-#define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads
+#define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads,
+                           // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads
 #endif
 #ifndef HH_KA_WPS
 #define HH_KA_WPS 6        // K_A: waves per SIMD the register allocator must leave room for (3 workgroups per CU)
@@ -618,15 +619,15 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = in[(size_t)row * N + t + m * T];
 #endif
-    fft_lanes<N>(v, TwRegs{tw}, t, buf);  // v[m] = C[kx = t + m*T]
+    if (!(HH_ABLATE & 16)) fft_lanes<N>(v, TwRegs{tw}, t, buf);  // v[m] = C[kx = t + m*T]
 
     if (row == 0) continue;  // the packed row is un-packed after the loop
     if constexpr (EPI == EPI_SCORE) {
       const float2* const wrow = a.w2 + (size_t)row * N;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        const float2 w = wrow[t + m * T];
-        const float q = amp_to_q<LOG>(v[m]);
+        const float2 w = (HH_ABLATE & 64) ? make_float2(1.f, 0.5f) : wrow[t + m * T];
+        const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
         s1 += w.x * q;
         s2 += w.x * q * q;
         s3 += w.y * q;
@@ -880,7 +881,8 @@ struct hh_ctx {
   bool have_geom = false;
   DevGeom geom{};
 
-  bool profiling = false;
+  int profiling = 0;             // 0 off, k > 0: time every k-th batch of a sweep
+  bool prof_now = false;         // the batch being enqueued is a sampled one
   std::vector<EventPair> events;
   size_t events_used = 0;
   int64_t prof_candidates = 0;
@@ -917,7 +919,7 @@ struct ProfScope {  // hipEvent pair around one launch when profiling is on
   hh_ctx* c;
   EventPair* ep = nullptr;
   ProfScope(hh_ctx* ctx, int kind) : c(ctx) {
-    if (!c->profiling) return;
+    if (!c->prof_now) return;
     if (c->events_used == c->events.size()) {
       EventPair p{};
       if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
@@ -1041,8 +1043,11 @@ int spectra_of_images(hh_ctx* c, int count) {
 
 int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
   const int nblk = nblk_for(c->n);
-  for (int64_t g0 = 0; g0 < g; g0 += c->max_batch) {
+  int64_t batch_no = 0;
+  for (int64_t g0 = 0; g0 < g; g0 += c->max_batch, ++batch_no) {
     const int nb = (int)std::min<int64_t>(c->max_batch, g - g0);
+    c->prof_now = c->profiling > 0 && (batch_no % c->profiling) == 0;
+    if (c->prof_now) c->prof_candidates += nb;
     FirstArgs fa{};
     fa.params = d_params + 4 * g0;
     fa.units = c->d_units;
@@ -1068,7 +1073,7 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
       HH_HIP(c, hipGetLastError());
     }
   }
-  c->prof_candidates += g;
+  c->prof_now = false;
   return HH_OK;
 }
 
@@ -1519,7 +1524,7 @@ int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
 
 int hh_profile_enable(hh_ctx* c, int on) {
   if (!c) return HH_ERR_ARG;
-  c->profiling = on != 0;
+  c->profiling = on > 0 ? on : 0;
   return HH_OK;
 }
 

@@ -207,9 +207,10 @@ class SweepEngine:
         return self._pair(a, b, "hh_cosine_similarity", "hh_cosine_similarity_f64")
 
     # -- profiling --------------------------------------------------------------------------
-    def profile(self, enable: bool):
+    def profile(self, period: int):
+        """0 = off; k >= 1 = record HIP events around the launches of every k-th batch."""
         with self._lock:
-            self._check(self._L.hh_profile_enable(self._ctx, 1 if enable else 0))
+            self._check(self._L.hh_profile_enable(self._ctx, int(period)))
             self._check(self._L.hh_profile_reset(self._ctx))
 
     def profile_get(self) -> dict:

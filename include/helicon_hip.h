@@ -63,8 +63,10 @@ typedef struct hh_geom {
                               `rot` is added; may be NULL when n_units <= 1                 */
 } hh_geom;
 
-/* Per-kernel device time of the calls since the last hh_profile_reset (HIP events recorded
- * on the context's stream around every launch while profiling is enabled). */
+/* Per-kernel device time of the sampled launches since the last hh_profile_reset: while
+ * profiling is enabled with period k (hh_profile_enable(ctx, k), k >= 1) HIP events are recorded
+ * on the context's stream around every launch of every k-th batch of a sweep.  Event records
+ * break the back-to-back issue of kernels (about 12 % of a sweep at k = 1), hence the sampling. */
 typedef struct hh_profile {
   double ms_first_pass;    /* raster + column FFT kernel                               */
   double ms_second_pass;   /* row FFT + |F| + log1p + masked moment reduction kernel   */
@@ -74,7 +76,7 @@ typedef struct hh_profile {
   int64_t n_second_pass;
   int64_t n_finalize;
   int64_t n_centres;
-  int64_t candidates;      /* candidates scored                                        */
+  int64_t candidates;      /* candidates in the sampled launches                       */
 } hh_profile;
 
 int hh_abi_version(void);

@@ -1,14 +1,15 @@
 #!/bin/bash
-# usage: tools_variants.sh <steps> "<bench args>" lib1.so lib2.so ...   (run on the GPU box)
+# usage: tools/variants.sh <steps> "<bench args>" lib1.so lib2.so ...   (run on the GPU box)
+# environment variables (e.g. HELICON_HIP_OVERLAP) pass through to bench.py
 steps=$1; shift
 extra=$1; shift
 for lib in "$@"; do
   HELICON_HIP_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps $steps --warmup 1 --no-cpu-baseline $extra 2>/dev/null | python -c "
-import sys, json
+import sys, json, os
 for line in sys.stdin:
     line=line.strip()
     if not line.startswith('{'): continue
     d=json.loads(line); k=d['roofline']['kernels']
-    print('$lib', '$extra', 'cand/s=%.0f' % d['value'], 'KA=%.1fus' % k['first_pass']['avg_us'], 'KB=%.1fus' % k['second_pass']['avg_us'], 'batch', d['config']['batch'], 'truth', d['argmax']['is_truth'])
+    print('$lib', '$extra', 'ov=' + os.environ.get('HELICON_HIP_OVERLAP','-'), 'cand/s=%.0f' % d['value'], 'KA=%.1fus' % k['first_pass']['avg_us'], 'KB=%.1fus' % k['second_pass']['avg_us'], 'batch', d['config']['batch'], 'truth', d['argmax']['is_truth'])
 " || exit 1
 done
