@@ -328,11 +328,11 @@ struct KA {
 
 // Add to the group's two packed columns every centre of cent[0..count) whose truncated footprint
 // reaches them.  The pixels live in the lanes' FFT input registers: lane t owns rows t + m*T
-// (m < 8) of both columns as v[m].x / v[m].y, so the raster needs no LDS image, no zero fill and
+// (m < 8) of both columns as r[2m] / r[2m+1] (= v[m].x / v[m].y), so the raster needs no LDS image, no zero fill and
 // no atomics; a centre's 2R+1 rows touch at most two register slots when T = 64.  Centres are
 // visited in lattice order, so every pixel's sum has a fixed order.
 template <int N>
-__device__ __forceinline__ void raster_pair(float2 (&v)[8], const float2* cent, int count, const DevGeom& g, int xa,
+__device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, int count, const DevGeom& g, int xa,
                                             int t, int lane) {
   constexpr int T = N / 8, TL = T < 64 ? T : 64;
   const int gbase = T >= 64 ? 0 : lane - t;
@@ -384,11 +384,21 @@ __device__ __forceinline__ void raster_pair(float2 (&v)[8], const float2* cent, 
         const float py = (rowok && colb) ? __expf(-(eb + d2) * g.inv_sigma2) : 0.f;
         const float ax = in_a ? px : 0.f, ay = in_a ? py : 0.f;
         const float bx = in_a ? 0.f : px, by = in_a ? 0.f : py;
+        if constexpr (T >= 64) {
+          // m0 is wave-uniform: the two slots are addressed with the VGPR index register
+          // (s_set_gpr_idx), 4 indexed adds instead of 32 weighted FMAs
+          const int i0 = __builtin_amdgcn_readfirstlane(m0), i1 = i0 < 7 ? i0 + 1 : 7;
+          r[2 * i0] += ax;
+          r[2 * i0 + 1] += ay;
+          r[2 * i1] += bx;      // bx = by = 0 whenever slot m0 + 1 would be past the image
+          r[2 * i1 + 1] += by;
+        } else {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const float sa = (m == m0) ? 1.f : 0.f, sb = (m == m0 + 1) ? 1.f : 0.f;
-          v[m].x = fmaf(sa, ax, fmaf(sb, bx, v[m].x));
-          v[m].y = fmaf(sa, ay, fmaf(sb, by, v[m].y));
+          for (int m = 0; m < 8; ++m) {
+            const float sa = (m == m0) ? 1.f : 0.f, sb = (m == m0 + 1) ? 1.f : 0.f;
+            r[2 * m] = fmaf(sa, ax, fmaf(sb, bx, r[2 * m]));
+            r[2 * m + 1] = fmaf(sa, ay, fmaf(sb, by, r[2 * m + 1]));
+          }
         }
       }
     }
@@ -418,8 +428,9 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
     const int xa = x0 + 2 * f;
     float2 v[8];
     if constexpr (MODE != MODE_IMAGE) {
+      float r[16];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = make_float2(0.f, 0.f);
+      for (int m = 0; m < 16; ++m) r[m] = 0.f;
       // one pass over the LDS centre list; if the band has more candidate centres than the list
       // holds they are streamed through it in chunks (workgroup-uniform trip count)
 #pragma unroll 1
@@ -430,8 +441,10 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
           fill_centres(cent, c, g, a.units, cb, cnt, tid, K::THREADS);
           __syncthreads();
         }
-        if (!(HH_ABLATE & 1)) raster_pair<N>(v, cent, cnt, g, xa, t, tid & 63);
+        if (!(HH_ABLATE & 1)) raster_pair<N>(r, cent, cnt, g, xa, t, tid & 63);
       }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = make_float2(r[2 * m], r[2 * m + 1]);
       if constexpr (MODE == MODE_RASTER_OUT) {
 #pragma unroll
         for (int m = 0; m < 8; ++m)
