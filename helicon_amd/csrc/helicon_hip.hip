@@ -36,6 +36,9 @@
 #ifndef HH_KA_WPS
 #define HH_KA_WPS 6        // K_A: waves per SIMD the register allocator must leave room for (3 workgroups per CU)
 #endif
+#ifndef HH_KB_TWLDS
+#define HH_KB_TWLDS 0      // K_B: twiddles from a per-workgroup LDS table instead of registers
+#endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
 #endif
@@ -578,7 +581,8 @@ struct KB {
   static constexpr int ITERS = RPW / GROUPS;
   static constexpr int NBLK = ROWS / RPW;
   static constexpr int BUF = N + N / 8;
-  static constexpr size_t LDS = (size_t)GROUPS * BUF * sizeof(float2);
+  static constexpr size_t LDS_FFT = (size_t)GROUPS * BUF * sizeof(float2);
+  static constexpr size_t LDS = LDS_FFT + (HH_KB_TWLDS ? (size_t)TwN<N>::total * T * sizeof(float2) : 0);
   static constexpr int WAVES_PER_SIMD = HH_KB_WPS;  // register budget (512 / WPS VGPRs)
   static_assert(ITERS >= 1 && ITERS * GROUPS == RPW, "row tiling");
 };
@@ -606,8 +610,21 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
   const float2* const in = a.inter + b * (size_t)K::ROWS * N;
   const int row0 = blockIdx.x * K::RPW + gi;  // this group's rows: row0 + it * GROUPS
 
+#if HH_KB_TWLDS
+  float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_FFT);
+  if (gi == 0) {
+    float2 twr[TwN<N>::total];
+    load_twiddles<N>(twr, t, a.twtab);
+#pragma unroll
+    for (int i = 0; i < TwN<N>::total - 1; ++i) twl[i * T + t] = twr[i];
+  }
+  __syncthreads();
+  const TwLds<T> twsrc{twl + t};
+#else
   float2 tw[TwN<N>::total];
   load_twiddles<N>(tw, t, a.twtab);
+  const TwRegs twsrc{tw};
+#endif
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 
 #if HH_KB_PREFETCH
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = in[(size_t)row * N + t + m * T];
 #endif
-    if (!(HH_ABLATE & 16)) fft_lanes<N>(v, TwRegs{tw}, t, buf);  // v[m] = C[kx = t + m*T]
+    if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
 
     if (row == 0) continue;  // the packed row is un-packed after the loop
     if constexpr (EPI == EPI_SCORE) {
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = in[t + m * T];
-    fft_lanes<N>(v, TwRegs{tw}, t, buf);
+    fft_lanes<N>(v, twsrc, t, buf);
 #pragma unroll
     for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
     group_sync<T>();
