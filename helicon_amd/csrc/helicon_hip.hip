@@ -39,6 +39,12 @@
 #ifndef HH_KB_TWLDS
 #define HH_KB_TWLDS 0      // K_B: twiddles from a per-workgroup LDS table instead of registers
 #endif
+#ifndef HH_KA_BAND
+#define HH_KA_BAND 64       // K_A: image columns per workgroup (N >= 256)
+#endif
+#ifndef HH_KB_BPW
+#define HH_KB_BPW 16       // K_B: ky blocks (of 8 rows) per workgroup
+#endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
 #endif
@@ -302,10 +308,20 @@ struct FirstArgs {
   const double* units;    // [n_units][3] (radius A, azimuth rad, axial A)
   const float* images;    // [B][N][N] (image mode)
   const float2* twtab;    // [N]
-  float2* inter;          // [B][N/2][N]
+  float2* inter;          // [B] x line-blocked half spectrum (inter_index)
   float* raster_out;      // optional [B][N][N]
   DevGeom g;
 };
+
+// Intermediate half spectrum of one candidate, N/2 x N complex64 in a line-blocked layout:
+//   H[kb = ky / 8][pair = x / 2][r = ky % 8][x % 2]
+// i.e. one 128-byte line holds eight consecutive ky of one pair of image columns.  K_A's
+// wavefronts own column pairs and write whole lines; K_B reads a block of eight ky (N/2 lines,
+// contiguous) and transposes it through LDS.  Returns the complex-element index of (ky, pair, 0).
+template <int N>
+__host__ __device__ constexpr size_t inter_index(int ky, int pair) {
+  return ((size_t)((ky >> 3) * (N / 2) + pair) * 8 + (ky & 7)) * 2;
+}
 
 constexpr int MODE_RASTER = 0, MODE_IMAGE = 1, MODE_RASTER_OUT = 2;  // 2: also store the raster image
 
@@ -315,17 +331,15 @@ struct KA {
   static constexpr int FPW = 8;              // FFTs per workgroup and tile
   static constexpr int COLS = 2 * FPW;       // image columns per tile
   static constexpr int THREADS = FPW * T;    // == N
-  static constexpr int NQ = N >= 256 ? N / 128 : 1;      // workgroups per candidate
+  static constexpr int NQ = N >= 256 ? (N / HH_KA_BAND > 0 ? N / HH_KA_BAND : 1) : 1;  // workgroups per candidate
   static constexpr int TPW = (N / COLS) / NQ;            // tiles per workgroup
   static constexpr int BAND = TPW * COLS;                // image columns per workgroup
   static constexpr int BUF = N + N / 8;      // padded complex slots per FFT buffer
-  static constexpr int STAGE_ROW = COLS + 2; // complex slots per staging row (+16 B pad)
   static constexpr int CL = 1024;            // lattice centres held in LDS at a time
   static constexpr size_t LDS_FFT = (size_t)FPW * BUF * sizeof(float2);
   static constexpr size_t LDS_CENT = (size_t)CL * sizeof(float2);
   static constexpr size_t LDS_TW = (size_t)TwN<N>::total * T * sizeof(float2);  // [slot][lane]
   static constexpr size_t LDS = LDS_FFT + LDS_CENT + LDS_TW;
-  static_assert((size_t)(N / 2) * STAGE_ROW * sizeof(float2) <= LDS_FFT, "staging tile must alias the FFT buffers");
   static_assert(TPW * NQ * COLS == N, "column tiling");
 };
 
@@ -475,23 +489,17 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
       ab[m] = make_float4(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y), 0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
     }
     if (t == 0) ab[0] = make_float4(v[0].x, v[4].x, v[0].y, v[4].y);
-    __syncthreads();  // every group is done with its FFT buffer: reuse LDS as the staging tile
-    float2* const stage = bufs;
+    // Store the pair's 2 x N/2 values in the line-blocked layout H[ky/8][pair][ky%8][2]: eight
+    // consecutive lanes (eight consecutive ky) fill one 128-byte line, so a wavefront writes whole
+    // lines by itself and the tile loop needs no workgroup barrier and no staging tile.
+    float2* const out = a.inter + b * (size_t)(N / 2) * N;
+    const int pair = (x0 >> 1) + f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < ((HH_ABLATE & 4) ? 1 : 4); ++m) {
       const int k = t + m * T;
-      *reinterpret_cast<float4*>(stage + k * K::STAGE_ROW + 2 * f) = ab[m];
+      *reinterpret_cast<float4*>(out + inter_index<N>(k, pair)) = ab[m];
     }
-    __syncthreads();
-    float2* const out = a.inter + b * (size_t)(N / 2) * N + x0;
-#pragma unroll
-    for (int p = 0; p < ((HH_ABLATE & 4) ? 1 : 4); ++p) {
-      const int idx = p * K::THREADS + tid;  // (N/2) rows x 8 float4
-      const int row = idx >> 3, c4 = idx & 7;
-      const float4 val = *reinterpret_cast<const float4*>(stage + row * K::STAGE_ROW + 2 * c4);
-      *reinterpret_cast<float4*>(out + (size_t)row * N + 2 * c4) = val;
-    }
-    __syncthreads();  // the staging tile is read out before the next tile's buffers are zeroed
+    group_sync<T>();  // the mirror reads above are done before the next tile's exchange writes
   }
 }
 
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
 // K_B: row FFT + amplitude + masked moments (or: store the half-plane spectrum)
 // ------------------------------------------------------------------------------------------
 struct SecondArgs {
-  const float2* inter;    // [B][N/2][N]
+  const float2* inter;    // [B] x line-blocked half spectrum (inter_index)
   const float2* twtab;    // [N]
   const float2* w2;       // [N/2+1][N] {w, w*(E-Ebar)}       (EPI_SCORE)
   double* partials;       // [B][NBLK][3]                      (EPI_SCORE)
@@ -573,18 +581,21 @@ constexpr int EPI_SCORE = 0, EPI_STORE = 1;
 
 template <int N>
 struct KB {
-  static constexpr int T = N / 8;
+  static constexpr int T = N / 8;             // lanes per FFT
+  static constexpr int GROUPS = 8;            // one group per row of a ky block
+  static constexpr int THREADS = GROUPS * T;  // == N
   static constexpr int ROWS = N / 2;
-  static constexpr int THREADS = (ROWS * T < 256) ? ROWS * T : 256;
-  static constexpr int GROUPS = THREADS / T;
-  static constexpr int RPW = ROWS < 32 ? ROWS : 32;  // rows per workgroup
-  static constexpr int ITERS = RPW / GROUPS;
-  static constexpr int NBLK = ROWS / RPW;
+  static constexpr int NKB = ROWS / 8;        // ky blocks per candidate
+  static constexpr int BPW = NKB < HH_KB_BPW ? NKB : HH_KB_BPW;  // ky blocks per workgroup
+  static constexpr int RPW = 8 * BPW;         // rows per workgroup
+  static constexpr int NBLK = NKB / BPW;      // workgroups per candidate
   static constexpr int BUF = N + N / 8;
+  static constexpr int PROW = N + 2;          // complex slots per panel row (+16 B: conflict-free b128 writes)
+  static constexpr size_t LDS_PANEL = (size_t)8 * PROW * sizeof(float2);
   static constexpr size_t LDS_FFT = (size_t)GROUPS * BUF * sizeof(float2);
-  static constexpr size_t LDS = LDS_FFT + (HH_KB_TWLDS ? (size_t)TwN<N>::total * T * sizeof(float2) : 0);
+  static constexpr size_t LDS = LDS_PANEL + LDS_FFT + (HH_KB_TWLDS ? (size_t)TwN<N>::total * T * sizeof(float2) : 0);
   static constexpr int WAVES_PER_SIMD = HH_KB_WPS;  // register budget (512 / WPS VGPRs)
-  static_assert(ITERS >= 1 && ITERS * GROUPS == RPW, "row tiling");
+  static_assert(NBLK * BPW == NKB, "row tiling");
 };
 
 // q = log1p(|F|) or |F| (transforms.py:807-810).  v_sqrt_f32 / v_log_f32 are 1-ulp hardware
@@ -598,20 +609,21 @@ __device__ __forceinline__ float amp_to_q(float2 f) {
 }
 
 template <int N, int EPI, int LOG>
-__global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_second_pass(SecondArgs a) {
+__global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD : 1)) void k_second_pass(SecondArgs a) {
   using K = KB<N>;
   constexpr int T = K::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2* const bufs = reinterpret_cast<float2*>(smem);
+  float2* const panel = reinterpret_cast<float2*>(smem);
+  float2* const bufs = reinterpret_cast<float2*>(smem + K::LDS_PANEL);
   const int tid = threadIdx.x;
-  const int gi = tid / T, t = tid % T;
+  const int gi = tid / T, t = tid % T;  // group gi owns row gi of every ky block
   float2* const buf = bufs + gi * K::BUF;
   const size_t b = blockIdx.y;
   const float2* const in = a.inter + b * (size_t)K::ROWS * N;
-  const int row0 = blockIdx.x * K::RPW + gi;  // this group's rows: row0 + it * GROUPS
+  const int kb0 = blockIdx.x * K::BPW;
 
 #if HH_KB_TWLDS
-  float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_FFT);
+  float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_PANEL + K::LDS_FFT);
   if (gi == 0) {
     float2 twr[TwN<N>::total];
     load_twiddles<N>(twr, t, a.twtab);
@@ -627,30 +639,41 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
 #endif
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 
-#if HH_KB_PREFETCH
-  float2 nxt[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) nxt[m] = in[(size_t)row0 * N + t + m * T];
-#endif
+  // A ky block is N/2 lines = 4N 16-byte pieces, contiguous in memory: piece q = pair*8 + r holds
+  // H[ky = 8 kb + r][x = 2 pair, 2 pair + 1].  Every thread moves 4 pieces (coalesced 16 B/lane).
+  // (four named registers, not an array: hipcc puts a conditionally re-loaded float4 array in scratch)
+  float4 ld0, ld1, ld2, ld3;
+  {
+    const float4* src = reinterpret_cast<const float4*>(in + (size_t)kb0 * 8 * N) + tid;
+    ld0 = src[0];
+    ld1 = src[K::THREADS];
+    ld2 = src[2 * K::THREADS];
+    ld3 = src[3 * K::THREADS];
+  }
+  // piece q = i * THREADS + tid -> panel slot of (r = q % 8, pair = q / 8)
+  auto slot = [&](int i) { const int q = i * K::THREADS + tid; return (q & 7) * K::PROW + 2 * (q >> 3); };
 
 #pragma unroll 1
-  for (int it = 0; it < K::ITERS; ++it) {
-    const int row = row0 + it * K::GROUPS;
+  for (int blk = 0; blk < K::BPW; ++blk) {
+    // transpose through LDS: panel[r][x]
+    *reinterpret_cast<float4*>(panel + slot(0)) = ld0;
+    *reinterpret_cast<float4*>(panel + slot(1)) = ld1;
+    *reinterpret_cast<float4*>(panel + slot(2)) = ld2;
+    *reinterpret_cast<float4*>(panel + slot(3)) = ld3;
+    __syncthreads();
     float2 v[8];
-#if HH_KB_PREFETCH
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = nxt[m];
-    if (it + 1 < K::ITERS) {  // next row's loads fly under this row's butterflies
-      const float2* const src = in + (size_t)(row + K::GROUPS) * N;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) nxt[m] = src[t + m * T];
+    for (int m = 0; m < 8; ++m) v[m] = panel[gi * K::PROW + t + m * T];
+    __syncthreads();  // the panel may be overwritten; the next block's loads fly under this FFT
+    if (blk + 1 < K::BPW) {
+      const float4* src = reinterpret_cast<const float4*>(in + (size_t)(kb0 + blk + 1) * 8 * N) + tid;
+      ld0 = src[0];
+      ld1 = src[K::THREADS];
+      ld2 = src[2 * K::THREADS];
+      ld3 = src[3 * K::THREADS];
     }
-#else
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = in[(size_t)row * N + t + m * T];
-#endif
+    const int row = (kb0 + blk) * 8 + gi;
     if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
-
     if (row == 0) continue;  // the packed row is un-packed after the loop
     if constexpr (EPI == EPI_SCORE) {
       const float2* const wrow = a.w2 + (size_t)row * N;
@@ -671,11 +694,14 @@ __global__ __launch_bounds__(KB<N>::THREADS, KB<N>::WAVES_PER_SIMD) void k_secon
 
   // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]); un-pack it into the
   // ky = 0 and ky = N/2 rows.  Done once per candidate, outside the row loop, by the first
-  // transform group(s) of workgroup 0 (all lanes of a T > 64 group's workgroup take the barriers).
+  // transform group of workgroup 0 (all lanes of a T > 64 group's workgroup take the barriers).
   if (blockIdx.x == 0 && (gi == 0 || T > 64)) {
     float2 v[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = in[t + m * T];
+    for (int m = 0; m < 8; ++m) {
+      const int x = t + m * T;
+      v[m] = in[inter_index<N>(0, x >> 1) + (x & 1)];
+    }
     fft_lanes<N>(v, twsrc, t, buf);
 #pragma unroll
     for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
@@ -844,32 +870,30 @@ __global__ void k_pair_sums(const T* __restrict__ x, const T* __restrict__ y, in
 // byte count, so rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes for THESE shapes
 // (MI355X_MICROARCH.md, HBM: FETCH_SIZE is only calibrated for 16-B-per-lane streams)
 // ------------------------------------------------------------------------------------------
-// mode 0: K_B's read shape — every wavefront reads 4 KB rows as 8 x (64 lanes x 8 B)
-__global__ __launch_bounds__(256) void k_calib_read(const float2* __restrict__ src, size_t rows, float* __restrict__ sink) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// mode 0: K_B's read shape — a workgroup streams 32 KB ky blocks, 16 B per lane, contiguous
+__global__ __launch_bounds__(512) void k_calib_read(const float4* __restrict__ src, size_t blocks, float* __restrict__ sink) {
   float acc = 0.f;
-  for (size_t r = (size_t)blockIdx.x * 4 + wave; r < rows; r += (size_t)gridDim.x * 4) {
-    const float2* p = src + r * 512 + lane;
+  for (size_t kb = blockIdx.x; kb < blocks; kb += gridDim.x) {
+    const float4* p = src + kb * 2048 + threadIdx.x;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const float2 x = p[m * 64];
-      acc += x.x + x.y;
+    for (int i = 0; i < 4; ++i) {
+      const float4 x = p[i * 512];
+      acc += x.x + x.y + x.z + x.w;
     }
   }
   if (acc == 123.456f) sink[0] = acc;  // keeps the loads alive, never true for the zero-filled buffer
 }
 
-// mode 1: K_A's write shape — 128-byte row segments (8 lanes x 16 B) at a 4 KB row pitch
-__global__ __launch_bounds__(512) void k_calib_write(float2* __restrict__ dst, size_t tiles) {
-  // one "tile" = 256 rows x 16 complex (32 KB), the staging tile of k_first_pass<512>
-  for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    float2* const out = dst + (tile / 32) * (size_t)256 * 512 + (tile % 32) * 16;
+// mode 1: K_A's write shape — each wavefront writes whole 128-byte lines (8 lanes x 16 B), the
+// lines of one store instruction 32 KB apart (one per ky block), as k_first_pass<512> does
+__global__ __launch_bounds__(512) void k_calib_write(float2* __restrict__ dst, size_t cands) {
+  const int t = threadIdx.x & 63, f = threadIdx.x >> 6;
+  for (size_t job = blockIdx.x; job < cands * 32; job += gridDim.x) {  // 32 tiles of 16 columns per candidate
+    float2* const out = dst + (job / 32) * (size_t)256 * 512;
+    const int pair = (int)(job % 32) * 8 + f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int idx = p * 512 + threadIdx.x;
-      const int row = idx >> 3, c4 = idx & 7;
-      *reinterpret_cast<float4*>(out + (size_t)row * 512 + 2 * c4) = make_float4(1.f, 2.f, 3.f, 4.f);
-    }
+    for (int m = 0; m < 4; ++m)
+      *reinterpret_cast<float4*>(out + inter_index<512>(t + 64 * m, pair)) = make_float4(1.f, 2.f, 3.f, 4.f);
   }
 }
 
@@ -1540,9 +1564,10 @@ int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
   hipError_t e = hipMemsetAsync(buf, 0, n_units * unit, c->stream);
   if (e == hipSuccess) {
     if (mode == 0)
-      hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(256), 0, c->stream, buf, n_units * 256, sink);
+      hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(512), 0, c->stream, reinterpret_cast<const float4*>(buf),
+                         n_units * 32, sink);
     else
-      hipLaunchKernelGGL(k_calib_write, dim3(2048), dim3(512), 0, c->stream, buf, n_units * 32);
+      hipLaunchKernelGGL(k_calib_write, dim3(2048), dim3(512), 0, c->stream, buf, n_units);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -135,8 +135,8 @@ int hh_profile_reset(hh_ctx* ctx);
 int hh_profile_get(hh_ctx* ctx, hh_profile* out);
 
 /* Profiling aid: one launch that moves `bytes` (rounded down to whole MiB) with the sweep's
- * read shape (mode 0: 8-byte-per-lane row reads of k_second_pass) or write shape (mode 1: 128-byte
- * row segments of k_first_pass), so rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a
+ * read shape (mode 0: contiguous 16-byte-per-lane block reads of k_second_pass) or write shape
+ * (mode 1: whole 128-byte lines, 8 lanes each, one line per ky block, as k_first_pass stores them), so rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a
  * known byte count for exactly these access patterns. */
 int hh_calibrate_traffic(hh_ctx* ctx, int mode, int64_t bytes);
 
