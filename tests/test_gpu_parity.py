@@ -289,3 +289,36 @@ def test_full_size_properties(n, apix, truth):
     pick = [17, 0, 1] if n == 512 else [17]
     ref = O.sweep_cpu(noisy, params[pick, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
     np.testing.assert_allclose(s1[pick], ref, rtol=0, atol=SCORE_TOL)
+
+
+def test_sweep_distributed_single_rank_rccl():
+    """The N > 1 code path (shard -> hh_sweep_device on torch's stream -> RCCL all-gather) on one GPU."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from helicon_amd.distributed import sweep_distributed
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, apix = 64, 2.0
+        imgs = np.stack([_noisy_helix(n, apix, 29.0, 10.0, 1, seed=s)[0] for s in range(2)])
+        d, br = 0.4 * n * apix, 2 * apix
+        grid = H.build_grid(np.arange(25.0, 33.5, 1.0), np.arange(8.0, 12.5, 1.0), (1, 2), tube_length=n * apix)
+        with H.SweepEngine(n, max_batch=16) as eng:
+            eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+            eng.set_reference(imgs)
+            full = sweep_distributed(eng, grid)
+            eng.set_stream(None)
+            ref = eng.sweep(grid.params)
+        assert full.shape == (2, len(grid))
+        np.testing.assert_array_equal(full, ref)
+    finally:
+        dist.destroy_process_group()
