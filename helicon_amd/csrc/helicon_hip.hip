@@ -300,6 +300,50 @@ __device__ __forceinline__ float2 centre_position(const Cand& c, const DevGeom& 
 }
 
 // ------------------------------------------------------------------------------------------
+// K_C: Pearson from moments.  Runs as its own tiny kernel, or (single-segment sweeps) as one
+// extra workgroup layer of the NEXT batch's k_first_pass, which saves a launch per batch.
+// ------------------------------------------------------------------------------------------
+struct RefConsts {
+  double sw;     // sum of weights = number of masked bins on the full plane
+  double swec;   // sum of the float32-rounded w*(E-Ebar) (exactly what K_B multiplies by)
+  double var_e;  // sum w (E-Ebar)^2
+};
+
+__device__ __forceinline__ float finalize_one(const double* __restrict__ partials, int nblk, int64_t i,
+                                              const RefConsts& rc) {
+  double s1 = 0, s2 = 0, s3 = 0;
+  for (int k = 0; k < nblk; ++k) {
+    const double* p = partials + (i * nblk + k) * 3;
+    s1 += p[0];
+    s2 += p[1];
+    s3 += p[2];
+  }
+  double score = 0.0;
+  if (rc.sw > 0) {
+    const double var_q = s2 - s1 * s1 / rc.sw;
+    const double cov = s3 - (s1 / rc.sw) * rc.swec;
+    const double den = var_q * rc.var_e;
+    // analysis.py:796-797: zero variance -> 0.  The float32 moments leave O(1e-7) relative
+    // rounding in var_q, so "zero" is a relative test.
+    if (den > 0 && var_q > 1e-9 * s2) score = cov / sqrt(den);
+  }
+  return (float)score;
+}
+
+__global__ void k_finalize(const double* __restrict__ partials, int nblk, int64_t n, RefConsts rc,
+                           float* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scores[i] = finalize_one(partials, nblk, i, rc);
+}
+
+struct FinArgs {  // finalize of the previous batch, folded into k_first_pass (n == 0: nothing to do)
+  const double* partials;
+  float* scores;
+  int n, nblk;
+  RefConsts rc;
+};
+
+// ------------------------------------------------------------------------------------------
 // K_A: raster (or image load) + column FFT.  A workgroup owns a band of image columns of one
 // candidate and walks it in tiles of 16 columns (8 transforms of 2 packed columns each).
 // ------------------------------------------------------------------------------------------
@@ -310,6 +354,7 @@ struct FirstArgs {
   const float2* twtab;    // [N]
   float2* inter;          // [B] x line-blocked half spectrum (inter_index)
   float* raster_out;      // optional [B][N][N]
+  FinArgs fin;            // previous batch's scores (one extra workgroup layer, blockIdx.y == B)
   DevGeom g;
 };
 
@@ -516,6 +561,15 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
   const int band0 = blockIdx.x * K::BAND;
   const size_t b = blockIdx.y;
   const DevGeom& g = a.g;
+
+  if constexpr (MODE == MODE_RASTER) {
+    if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {  // the extra layer: scores of the previous batch
+      if (blockIdx.x == 0)
+        for (int i = tid; i < a.fin.n; i += K::THREADS)
+          a.fin.scores[i] = finalize_one(a.fin.partials, a.fin.nblk, i, a.fin.rc);
+      return;
+    }
+  }
 
   // Lattice centres that can reach this band of columns -> LDS, once per workgroup.  The axial
   // coordinate of centre (i, s, u) is m5 * i * rise + O(slack), so only a window of subunit
@@ -764,38 +818,6 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
 }
 
 // ------------------------------------------------------------------------------------------
-// K_C: Pearson from moments
-// ------------------------------------------------------------------------------------------
-struct RefConsts {
-  double sw;     // sum of weights = number of masked bins on the full plane
-  double swec;   // sum of the float32-rounded w*(E-Ebar) (exactly what K_B multiplies by)
-  double var_e;  // sum w (E-Ebar)^2
-};
-
-__global__ void k_finalize(const double* __restrict__ partials, int nblk, int64_t n, RefConsts rc,
-                           float* __restrict__ scores) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s1 = 0, s2 = 0, s3 = 0;
-  for (int k = 0; k < nblk; ++k) {
-    const double* p = partials + (i * nblk + k) * 3;
-    s1 += p[0];
-    s2 += p[1];
-    s3 += p[2];
-  }
-  double score = 0.0;
-  if (rc.sw > 0) {
-    const double var_q = s2 - s1 * s1 / rc.sw;
-    const double cov = s3 - (s1 / rc.sw) * rc.swec;
-    const double den = var_q * rc.var_e;
-    // analysis.py:796-797: zero variance -> 0.  The float32 moments leave O(1e-7) relative
-    // rounding in var_q, so "zero" is a relative test.
-    if (den > 0 && var_q > 1e-9 * s2) score = cov / sqrt(den);
-  }
-  scores[i] = (float)score;
-}
-
-// ------------------------------------------------------------------------------------------
 // spectrum expansion for hh_power_spectrum, and the vector reductions
 // ------------------------------------------------------------------------------------------
 __global__ void k_expand_spectrum(const float2* __restrict__ spec, int n, int log_flag, float* __restrict__ pwr,
@@ -998,7 +1020,8 @@ int launch_first(hh_ctx* c, const FirstArgs& a, int batch) {
     attr_done = true;
   }
   ProfScope ps(c, 0);
-  hipLaunchKernelGGL((k_first_pass<N, MODE>), dim3(K::NQ, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  hipLaunchKernelGGL((k_first_pass<N, MODE>), dim3(K::NQ, batch + (a.fin.n > 0 ? 1 : 0)), dim3(K::THREADS), K::LDS,
+                     c->stream, a);
   HH_HIP(c, hipGetLastError());
   return HH_OK;
 }
@@ -1097,6 +1120,8 @@ int spectra_of_images(hh_ctx* c, int count) {
 
 int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
   const int nblk = nblk_for(c->n);
+  const bool fold = c->n_segments == 1;  // scores of batch i are computed inside K_A of batch i + 1
+  FinArgs pending{};
   int64_t batch_no = 0;
   for (int64_t g0 = 0; g0 < g; g0 += c->max_batch, ++batch_no) {
     const int nb = (int)std::min<int64_t>(c->max_batch, g - g0);
@@ -1107,9 +1132,11 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     fa.units = c->d_units;
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
+    fa.fin = pending;
     fa.g = c->geom;
     int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
     if (rc) return rc;
+    pending = FinArgs{};
     for (int s = 0; s < c->n_segments; ++s) {
       SecondArgs sa{};
       sa.inter = c->d_inter;
@@ -1119,10 +1146,13 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
       sa.log_flag = c->log_flag;
       rc = dispatch_second<EPI_SCORE>(c, sa, nb);
       if (rc) return rc;
-      {
+      float* const out = d_scores + (size_t)s * g + g0;
+      if (fold && g0 + nb < g) {
+        pending = FinArgs{c->d_partials, out, nb, nblk, c->ref[s]};
+      } else {
         ProfScope ps(c, 2);
         hipLaunchKernelGGL(k_finalize, dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
-                           (int64_t)nb, c->ref[s], d_scores + (size_t)s * g + g0);
+                           (int64_t)nb, c->ref[s], out);
       }
       HH_HIP(c, hipGetLastError());
     }
