@@ -625,7 +625,7 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
 struct SecondArgs {
   const float2* inter;    // [B] x line-blocked half spectrum (inter_index)
   const float2* twtab;    // [N]
-  const float2* w2;       // [N/2+1][N] {w, w*(E-Ebar)}       (EPI_SCORE)
+  const float2* w2;       // [N/2+1][T][8] {w, w*(E-Ebar)} at kx = t + 64 m: a lane's 8 bins are contiguous (EPI_SCORE)
   double* partials;       // [B][NBLK][3]                      (EPI_SCORE)
   float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
   int log_flag;
@@ -727,17 +727,29 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
       ld3 = src[3 * K::THREADS];
     }
     const int row = (kb0 + blk) * 8 + gi;
+    // this row's weights: 64 contiguous bytes per lane, requested before the FFT so the (L2) latency
+    // is covered by the butterflies
+    float4 wq0, wq1, wq2, wq3;
+    if constexpr (EPI == EPI_SCORE) {
+      const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + t) * 8);
+      wq0 = wrow[0];
+      wq1 = wrow[1];
+      wq2 = wrow[2];
+      wq3 = wrow[3];
+    }
     if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
     if (row == 0) continue;  // the packed row is un-packed after the loop
     if constexpr (EPI == EPI_SCORE) {
-      const float2* const wrow = a.w2 + (size_t)row * N;
+      const float2 w[8] = {make_float2(wq0.x, wq0.y), make_float2(wq0.z, wq0.w), make_float2(wq1.x, wq1.y),
+                           make_float2(wq1.z, wq1.w), make_float2(wq2.x, wq2.y), make_float2(wq2.z, wq2.w),
+                           make_float2(wq3.x, wq3.y), make_float2(wq3.z, wq3.w)};
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        const float2 w = (HH_ABLATE & 64) ? make_float2(1.f, 0.5f) : wrow[t + m * T];
         const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
-        s1 += w.x * q;
-        s2 += w.x * q * q;
-        s3 += w.y * q;
+        const float wx = (HH_ABLATE & 64) ? 1.f : w[m].x, wy = (HH_ABLATE & 64) ? 0.5f : w[m].y;
+        s1 += wx * q;
+        s2 += wx * q * q;
+        s3 += wy * q;
       }
     } else {
       float2* const so = a.spec_out + (b * (size_t)(N / 2 + 1) + row) * N;
@@ -769,8 +781,8 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
         const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
         const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
         if constexpr (EPI == EPI_SCORE) {
-          const float2 w0 = a.w2[kx];
-          const float2 wn = a.w2[(size_t)(N / 2) * N + kx];
+          const float2 w0 = a.w2[(size_t)t * 8 + m];
+          const float2 wn = a.w2[((size_t)(N / 2) * T + t) * 8 + m];
           const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
           s1 += w0.x * q0 + wn.x * qn;
           s2 += w0.x * q0 * q0 + wn.x * qn * qn;
@@ -946,7 +958,7 @@ struct hh_ctx {
   float* d_scores = nullptr;
   int64_t cap_params = 0;
   double* d_units = nullptr;
-  float2* d_w2 = nullptr;        // [S][N/2+1][N]
+  float2* d_w2 = nullptr;        // [S][N/2+1][N/8][8] (lane-major within a row)
   float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
   int64_t cap_spec = 0;
   float* d_img = nullptr;        // scratch images
@@ -1442,7 +1454,10 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     for (size_t i = 0; i < nh; ++i) {
       const double dc = e[i] - ebar;
       const float wec = (float)((double)w[i] * dc);
-      w2[(size_t)s * nh + i] = make_float2(w[i], wec);
+      {  // device layout: within a row, lane t of the row's FFT finds its bins kx = t + T m at [t][m]
+        const size_t row = i / n, kx = i % n, tt = kx % (n / 8), mm = kx / (n / 8);
+        w2[(size_t)s * nh + row * n + tt * 8 + mm] = make_float2(w[i], wec);
+      }
       swec += (double)wec;
       var_e += (double)w[i] * dc * dc;
     }
