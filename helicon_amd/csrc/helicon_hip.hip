@@ -628,10 +628,11 @@ struct SecondArgs {
   const float2* w2;       // [N/2+1][T][8] {w, w*(E-Ebar)} at kx = t + 64 m: a lane's 8 bins are contiguous (EPI_SCORE)
   double* partials;       // [B][NBLK][3]                      (EPI_SCORE)
   float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
+  float* q_out;           // [B][N/2+1][N] masked q, natural order (EPI_QSTORE)
   int log_flag;
 };
 
-constexpr int EPI_SCORE = 0, EPI_STORE = 1;
+constexpr int EPI_SCORE = 0, EPI_STORE = 1, EPI_QSTORE = 2;  // 2: several segments — keep q for the contraction
 
 template <int N>
 struct KB {
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
     // this row's weights: 64 contiguous bytes per lane, requested before the FFT so the (L2) latency
     // is covered by the butterflies
     float4 wq0, wq1, wq2, wq3;
-    if constexpr (EPI == EPI_SCORE) {
+    if constexpr (EPI != EPI_STORE) {
       const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + t) * 8);
       wq0 = wrow[0];
       wq1 = wrow[1];
@@ -739,17 +740,21 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
     }
     if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
     if (row == 0) continue;  // the packed row is un-packed after the loop
-    if constexpr (EPI == EPI_SCORE) {
+    if constexpr (EPI != EPI_STORE) {
       const float2 w[8] = {make_float2(wq0.x, wq0.y), make_float2(wq0.z, wq0.w), make_float2(wq1.x, wq1.y),
                            make_float2(wq1.z, wq1.w), make_float2(wq2.x, wq2.y), make_float2(wq2.z, wq2.w),
                            make_float2(wq3.x, wq3.y), make_float2(wq3.z, wq3.w)};
+      float* const qrow = (EPI == EPI_QSTORE) ? a.q_out + (b * (size_t)(N / 2 + 1) + row) * N : nullptr;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
         const float wx = (HH_ABLATE & 64) ? 1.f : w[m].x, wy = (HH_ABLATE & 64) ? 0.5f : w[m].y;
         s1 += wx * q;
         s2 += wx * q * q;
-        s3 += wy * q;
+        if constexpr (EPI == EPI_QSTORE)
+          qrow[t + m * T] = wx > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
+        else
+          s3 += wy * q;
       }
     } else {
       float2* const so = a.spec_out + (b * (size_t)(N / 2 + 1) + row) * N;
@@ -780,13 +785,19 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
         const float2 cm = buf[lds_pad((N - kx) & (N - 1))];
         const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
         const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
-        if constexpr (EPI == EPI_SCORE) {
+        if constexpr (EPI != EPI_STORE) {
           const float2 w0 = a.w2[(size_t)t * 8 + m];
           const float2 wn = a.w2[((size_t)(N / 2) * T + t) * 8 + m];
           const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
           s1 += w0.x * q0 + wn.x * qn;
           s2 += w0.x * q0 * q0 + wn.x * qn * qn;
-          s3 += w0.y * q0 + wn.y * qn;
+          if constexpr (EPI == EPI_QSTORE) {
+            float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
+            q0row[kx] = w0.x > 0.f ? q0 : 0.f;
+            q0row[(size_t)(N / 2) * N + kx] = wn.x > 0.f ? qn : 0.f;
+          } else {
+            s3 += w0.y * q0 + wn.y * qn;
+          }
         } else {
           float2* const so = a.spec_out + b * (size_t)(N / 2 + 1) * N;
           so[kx] = f0;
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
     }
   }
 
-  if constexpr (EPI == EPI_SCORE) {
+  if constexpr (EPI != EPI_STORE) {
     // float partials (<= 64 terms per lane) -> float64 wave shuffle reduce -> LDS -> one triple
     double d1 = s1, d2 = s2, d3 = s3;
 #pragma unroll
@@ -827,6 +838,75 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
       o[2] = r3;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Several experimental segments against one candidate grid (BASELINE config 5): the covariance
+// numerators S3[s][c] = sum_k WEC[s][k] * Q[c][k] are a dense contraction over the K = (N/2+1) N
+// half-plane bins, so they run on the matrix cores with the exact-f32 MFMA (32x32x2, f32 in /
+// f32 accumulate): one wavefront owns a 64-candidate x 64-segment tile of ONE spectrum row (N bins)
+// and streams its operands straight from L2 / Infinity Cache into registers, 16 B per lane.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void k_segment_corr(const float* __restrict__ q /*[Bp][K]*/,
+                                                     const float* __restrict__ wec /*[Sp][K]*/, int n_k /*N*/,
+                                                     size_t K, int Bp, int Sp, float* __restrict__ part /*[rows][Bp][Sp]*/) {
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x;                 // spectrum row = K-slice of n_k bins
+  const int c0 = blockIdx.y * 64, s0 = blockIdx.z * 64;
+  const float* qa = q + (size_t)(c0 + i) * K + (size_t)row * n_k + 4 * h;
+  const float* qb = qa + (size_t)32 * K;
+  const float* wa = wec + (size_t)(s0 + i) * K + (size_t)row * n_k + 4 * h;
+  const float* wb = wa + (size_t)32 * K;
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  for (int k = 0; k < n_k; k += 8) {
+    const float4 a0 = *reinterpret_cast<const float4*>(qa + k), a1 = *reinterpret_cast<const float4*>(qb + k);
+    const float4 b0 = *reinterpret_cast<const float4*>(wa + k), b1 = *reinterpret_cast<const float4*>(wb + k);
+    // lane (i, h) supplies A[i][kk] and B[kk][i] for kk = k + 4h + j in step j: both operands use
+    // the same k numbering, which is all a dot product needs
+#define HH_STEP(C)                                                         \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b0.C, acc00, 0, 0, 0); \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b1.C, acc01, 0, 0, 0); \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b0.C, acc10, 0, 0, 0); \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b1.C, acc11, 0, 0, 0);
+    HH_STEP(x) HH_STEP(y) HH_STEP(z) HH_STEP(w)
+#undef HH_STEP
+  }
+  // D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* const out = part + (size_t)row * Bp * Sp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+    out[(size_t)(c0 + ci) * Sp + s0 + i] = acc00[r];
+    out[(size_t)(c0 + ci) * Sp + s0 + 32 + i] = acc01[r];
+    out[(size_t)(c0 + 32 + ci) * Sp + s0 + i] = acc10[r];
+    out[(size_t)(c0 + 32 + ci) * Sp + s0 + 32 + i] = acc11[r];
+  }
+}
+
+// scores[s][g0 + c] for one batch: moments s1, s2 from K_B's partials, s3 summed over spectrum rows
+__global__ void k_finalize_segments(const double* __restrict__ partials, int nblk, const float* __restrict__ part,
+                                    int rows, int Bp, int Sp, int nb, int n_seg, const RefConsts* __restrict__ rc,
+                                    float* __restrict__ scores, int64_t g, int64_t g0) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nb * n_seg) return;
+  const int cand = idx / n_seg, s = idx % n_seg;
+  double s1 = 0, s2 = 0, s3 = 0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += partials[((size_t)cand * nblk + k) * 3];
+    s2 += partials[((size_t)cand * nblk + k) * 3 + 1];
+  }
+  for (int r = 0; r < rows; ++r) s3 += (double)part[((size_t)r * Bp + cand) * Sp + s];
+  const RefConsts c = rc[s];
+  double score = 0.0;
+  if (c.sw > 0) {
+    const double var_q = s2 - s1 * s1 / c.sw;
+    const double cov = s3 - (s1 / c.sw) * c.swec;
+    const double den = var_q * c.var_e;
+    if (den > 0 && var_q > 1e-9 * s2) score = cov / sqrt(den);
+  }
+  scores[(size_t)s * g + g0 + cand] = (float)score;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -958,7 +1038,12 @@ struct hh_ctx {
   float* d_scores = nullptr;
   int64_t cap_params = 0;
   double* d_units = nullptr;
-  float2* d_w2 = nullptr;        // [S][N/2+1][N/8][8] (lane-major within a row)
+  float2* d_w2 = nullptr;        // [N/2+1][N/8][8] (lane-major within a row); with S > 1 only w is used
+  float* d_wec = nullptr;        // S > 1: [Sp][K] w (E_s - Ebar_s), natural bin order, Sp = S rounded up to 64
+  float* d_q = nullptr;          // S > 1: [Bp][K] masked q of one batch, Bp = max_batch rounded up to 64
+  float* d_cpart = nullptr;      // S > 1: [N/2+1][Bp][Sp] per-row covariance numerators
+  RefConsts* d_ref = nullptr;    // S > 1: [S]
+  int s_pad = 0, b_pad = 0;
   float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
   int64_t cap_spec = 0;
   float* d_img = nullptr;        // scratch images
@@ -1081,7 +1166,7 @@ int dispatch_second_n(hh_ctx* c, const SecondArgs& a, int batch) {
 
 template <int EPI>
 int dispatch_second(hh_ctx* c, const SecondArgs& a, int batch) {
-  if (EPI == EPI_SCORE && a.log_flag) return dispatch_second_n<EPI, 1>(c, a, batch);
+  if (EPI != EPI_STORE && a.log_flag) return dispatch_second_n<EPI, 1>(c, a, batch);
   return dispatch_second_n<EPI, 0>(c, a, batch);
 }
 
@@ -1132,7 +1217,6 @@ int spectra_of_images(hh_ctx* c, int count) {
 
 int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
   const int nblk = nblk_for(c->n);
-  const bool fold = c->n_segments == 1;  // scores of batch i are computed inside K_A of batch i + 1
   FinArgs pending{};
   int64_t batch_no = 0;
   for (int64_t g0 = 0; g0 < g; g0 += c->max_batch, ++batch_no) {
@@ -1149,23 +1233,38 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
     if (rc) return rc;
     pending = FinArgs{};
-    for (int s = 0; s < c->n_segments; ++s) {
-      SecondArgs sa{};
-      sa.inter = c->d_inter;
-      sa.twtab = c->d_tw;
-      sa.w2 = c->d_w2 + (size_t)s * (c->n / 2 + 1) * c->n;
-      sa.partials = c->d_partials;
-      sa.log_flag = c->log_flag;
+    SecondArgs sa{};
+    sa.inter = c->d_inter;
+    sa.twtab = c->d_tw;
+    sa.w2 = c->d_w2;
+    sa.partials = c->d_partials;
+    sa.log_flag = c->log_flag;
+    if (c->n_segments == 1) {
       rc = dispatch_second<EPI_SCORE>(c, sa, nb);
       if (rc) return rc;
-      float* const out = d_scores + (size_t)s * g + g0;
-      if (fold && g0 + nb < g) {
-        pending = FinArgs{c->d_partials, out, nb, nblk, c->ref[s]};
+      float* const out = d_scores + g0;
+      if (g0 + nb < g) {
+        pending = FinArgs{c->d_partials, out, nb, nblk, c->ref[0]};
       } else {
         ProfScope ps(c, 2);
         hipLaunchKernelGGL(k_finalize, dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
-                           (int64_t)nb, c->ref[s], out);
+                           (int64_t)nb, c->ref[0], out);
       }
+      HH_HIP(c, hipGetLastError());
+    } else {
+      // several segments: q of the batch -> HBM, one MFMA contraction against all segments' centred
+      // spectra, then Pearson per (segment, candidate)
+      sa.q_out = c->d_q;
+      rc = dispatch_second<EPI_QSTORE>(c, sa, nb);
+      if (rc) return rc;
+      const int rows = c->n / 2 + 1;
+      const size_t K = (size_t)rows * c->n;
+      ProfScope ps(c, 2);
+      hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
+                         c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
+      const int total = nb * c->n_segments;
+      hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
+                         c->d_cpart, rows, c->b_pad, c->s_pad, nb, c->n_segments, c->d_ref, d_scores, g, g0);
       HH_HIP(c, hipGetLastError());
     }
   }
@@ -1329,6 +1428,10 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_scores);
   (void)hipFree(c->d_units);
   (void)hipFree(c->d_w2);
+  (void)hipFree(c->d_wec);
+  (void)hipFree(c->d_q);
+  (void)hipFree(c->d_cpart);
+  (void)hipFree(c->d_ref);
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1438,7 +1541,13 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     }
   if (!(sw > 0)) return fail(c, HH_ERR_ARG, "hh_set_reference: the mask selects no Fourier bin");
 
-  std::vector<float2> w2((size_t)n_segments * nh);
+  // device tables: W2 (weights, and for one segment the centred spectrum, in K_B's lane-major order);
+  // with several segments the centred spectra go to a [Sp][K] matrix for the MFMA contraction
+  const bool multi = n_segments > 1;
+  const int s_pad = multi ? (n_segments + 63) / 64 * 64 : 0;
+  const int b_pad = multi ? (c->max_batch + 63) / 64 * 64 : 0;
+  std::vector<float2> w2(nh);
+  std::vector<float> wecm(multi ? (size_t)s_pad * nh : 0, 0.f);
   c->ref.assign(n_segments, RefConsts{});
   std::vector<double> e(nh);
   for (int s = 0; s < n_segments; ++s) {
@@ -1454,19 +1563,37 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     for (size_t i = 0; i < nh; ++i) {
       const double dc = e[i] - ebar;
       const float wec = (float)((double)w[i] * dc);
-      {  // device layout: within a row, lane t of the row's FFT finds its bins kx = t + T m at [t][m]
+      if (s == 0) {  // device layout: within a row, lane t of the row's FFT finds its bins kx = t + T m at [t][m]
         const size_t row = i / n, kx = i % n, tt = kx % (n / 8), mm = kx / (n / 8);
-        w2[(size_t)s * nh + row * n + tt * 8 + mm] = make_float2(w[i], wec);
+        w2[row * n + tt * 8 + mm] = make_float2(w[i], wec);
       }
+      if (multi) wecm[(size_t)s * nh + i] = wec;
       swec += (double)wec;
       var_e += (double)w[i] * dc * dc;
     }
     c->ref[s] = RefConsts{sw, swec, var_e};
   }
-  if (c->d_w2) HH_HIP(c, hipFree(c->d_w2));
+  for (void* p : {(void*)c->d_w2, (void*)c->d_wec, (void*)c->d_q, (void*)c->d_cpart, (void*)c->d_ref})
+    if (p) HH_HIP(c, hipFree(p));
   c->d_w2 = nullptr;
+  c->d_wec = nullptr;
+  c->d_q = nullptr;
+  c->d_cpart = nullptr;
+  c->d_ref = nullptr;
   HH_HIP(c, hipMalloc(&c->d_w2, w2.size() * sizeof(float2)));
   HH_HIP(c, hipMemcpyAsync(c->d_w2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+  if (multi) {
+    HH_HIP(c, hipMalloc(&c->d_wec, wecm.size() * sizeof(float)));
+    HH_HIP(c, hipMalloc(&c->d_q, (size_t)b_pad * nh * sizeof(float)));
+    HH_HIP(c, hipMalloc(&c->d_cpart, (size_t)(n / 2 + 1) * b_pad * s_pad * sizeof(float)));
+    HH_HIP(c, hipMalloc(&c->d_ref, (size_t)n_segments * sizeof(RefConsts)));
+    HH_HIP(c, hipMemcpyAsync(c->d_wec, wecm.data(), wecm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HH_HIP(c, hipMemcpyAsync(c->d_ref, c->ref.data(), (size_t)n_segments * sizeof(RefConsts), hipMemcpyHostToDevice,
+                             c->stream));
+    HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)b_pad * nh * sizeof(float), c->stream));  // pad rows stay finite
+  }
+  c->s_pad = s_pad;
+  c->b_pad = b_pad;
   HH_HIP(c, hipStreamSynchronize(c->stream));
   c->n_segments = n_segments;
   c->log_flag = log_flag ? 1 : 0;

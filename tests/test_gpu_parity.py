@@ -322,3 +322,27 @@ def test_sweep_distributed_single_rank_rccl():
         np.testing.assert_array_equal(full, ref)
     finally:
         dist.destroy_process_group()
+
+
+def test_many_segments_match_single_segment_sweeps():
+    """BASELINE config 5 in miniature: 70 segments (two 64-wide MFMA tiles) x 100 candidates (two
+    candidate tiles, the second one partial) must reproduce 70 independent single-segment sweeps."""
+    n, apix = 64, 2.0
+    rng = np.random.default_rng(11)
+    base, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1, sigma=0.0)
+    imgs = np.stack([(base + rng.normal(0, 0.4 * base.std(), base.shape)).astype(np.float32) for _ in range(70)])
+    tw = 29.0 + 0.1 * rng.integers(-30, 30, 100)
+    rs = 10.0 + 0.05 * rng.integers(-20, 20, 100)
+    params = np.stack([tw, rs, np.ones(100), np.zeros(100)], axis=1)
+    with H.SweepEngine(n, max_batch=80) as eng:
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        eng.set_reference(imgs)
+        multi = eng.sweep(params)
+        assert multi.shape == (70, 100)
+        for s in (0, 1, 31, 32, 63, 64, 69):
+            eng.set_reference(imgs[s])
+            single = eng.sweep(params)[0]
+            np.testing.assert_allclose(multi[s], single, rtol=0, atol=2e-6)
+    mask = O.radial_band_mask(n, n)
+    ref = O.sweep_cpu(imgs[69], params[:5, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(multi[69, :5], ref, rtol=0, atol=SCORE_TOL)
