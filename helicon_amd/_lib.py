@@ -59,6 +59,7 @@ EXPORTS = {
     "hh_max_batch": (C.c_int, [_ctx]),
     "hh_last_error": (C.c_char_p, [_ctx]),
     "hh_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "hh_use_own_stream": (C.c_int, [_ctx]),
     "hh_set_geometry": (C.c_int, [_ctx, C.POINTER(hh_geom)]),
     "hh_set_reference": (C.c_int, [_ctx, _f32p, C.c_int, C.POINTER(C.c_uint8), C.c_int]),
     "hh_sweep": (C.c_int, [_ctx, _f64p, C.c_int64, _f32p]),

@@ -1444,7 +1444,15 @@ int hh_set_stream(hh_ctx* c, void* hip_stream) {
   if (!c) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));
   HH_HIP(c, hipStreamSynchronize(c->stream));
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL is the device's null stream, a valid choice
+  return HH_OK;
+}
+
+int hh_use_own_stream(hh_ctx* c) {
+  if (!c) return HH_ERR_ARG;
+  HH_HIP(c, hipSetDevice(c->device));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = c->own_stream;
   return HH_OK;
 }
 

@@ -97,9 +97,13 @@ class SweepEngine:
 
     # -- configuration ----------------------------------------------------------------------
     def set_stream(self, hip_stream: int | None):
-        """Run on a caller-owned hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        """Run on a caller-owned hipStream_t given as an int (``torch.cuda.current_stream().cuda_stream``;
+        0 is the device's null stream = torch's default stream); ``None`` returns to the engine's own stream."""
         with self._lock:
-            self._check(self._L.hh_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+            if hip_stream is None:
+                self._check(self._L.hh_use_own_stream(self._ctx))
+            else:
+                self._check(self._L.hh_set_stream(self._ctx, C.c_void_p(int(hip_stream))))
 
     def set_geometry(self, *, apix, helical_diameter, ball_radius, tilt=0.0, psi=0.0, dy=0.0,
                      units=None, tail_bits=0):

@@ -91,8 +91,11 @@ int hh_max_batch(const hh_ctx* ctx);
 const char* hh_last_error(const hh_ctx* ctx);
 
 /* Run all later work of this context on `hip_stream` (a hipStream_t, e.g. torch's current
- * stream handle); NULL selects the context's own stream. */
+ * stream handle).  NULL means the device's null stream — what torch's default stream is — so
+ * work enqueued here is ordered with other work on that stream (e.g. an RCCL all-gather of the
+ * scores).  hh_use_own_stream returns to the context's private non-blocking stream (the default). */
 int hh_set_stream(hh_ctx* ctx, void* hip_stream);
+int hh_use_own_stream(hh_ctx* ctx);
 
 int hh_set_geometry(hh_ctx* ctx, const hh_geom* geom);
 
