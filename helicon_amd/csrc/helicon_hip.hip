@@ -591,16 +591,14 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
       c_lo = (ilo + c.imax) * per;
       c_hi = ihi < ilo ? c_lo : (ihi + c.imax + 1) * per;
     }
-    if (c_hi - c_lo <= K::CL) {
-      fill_centres(cent, c, g, a.units, c_lo, c_hi - c_lo, tid, K::THREADS);
-      __syncthreads();
-    }
+    if (c_hi - c_lo <= K::CL) fill_centres(cent, c, g, a.units, c_lo, c_hi - c_lo, tid, K::THREADS);
   }
   const bool resident = (c_hi - c_lo) <= K::CL;  // workgroup-uniform
 
-  // Twiddles: one LDS copy per workgroup, [slot][lane], written by the first transform group.
+  // Twiddles: one LDS copy per workgroup, [slot][lane], written by the LAST transform group while
+  // the first lanes are busy with the float64 centre list; one barrier publishes both.
   float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_FFT + K::LDS_CENT);
-  if (f == 0) {
+  if (f == K::FPW - 1) {
     float2 twr[TwN<N>::total];
     load_twiddles<N>(twr, t, a.twtab);
 #pragma unroll
