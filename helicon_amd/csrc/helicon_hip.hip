@@ -1376,7 +1376,7 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
     max_batch = (int)std::max<int64_t>(16, (256LL << 20) / ((int64_t)n * n * 4));
     max_batch = std::min(max_batch, 4096);
   }
-  if (max_batch > 65535) max_batch = 65535;  // gridDim.y
+  if (max_batch > 65534) max_batch = 65534;  // gridDim.y, plus the finalize layer of k_first_pass
   hh_ctx* c = new (std::nothrow) hh_ctx();
   if (!c) return fail(nullptr, HH_ERR_NOMEM, "hh_create: out of host memory");
   c->device = device;

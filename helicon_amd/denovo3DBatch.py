@@ -1,0 +1,84 @@
+"""Headless batch driver of the denovo3D parameter sweep.
+
+The reference's README lists a ``denovo3DBatch`` command (README.md:27) but ships no module for it;
+its interactive counterpart is ``run_denovo3D_reconstruction`` (src/helicon/webApps/denovo3D/app.py:
+2286-2452), whose grid construction (``np.arange(min, max + step/2, step)`` axes, twist-major
+``itertools.product``, wrap/round of the twist, skipped pairs) and result ordering (scores sorted
+descending, app.py:2521-2523) this driver reproduces without the Shiny UI.
+
+    python -m helicon_amd.denovo3DBatch image.npy --apix 2.0 --twist 25 33 0.2 --rise 8 13 0.2 \\
+           --csym 1 --out scores.npz [--mask mask.npy] [--no-log] [--device 0] [--top 10]
+
+Images are ``.npy`` arrays (``[N, N]`` or ``[S, N, N]``; square, side a power of two in 32…1024).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+
+import numpy as np
+
+from .denovo3D import sweep
+from .grid import sweep_axis
+
+
+def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
+    parser.add_argument("image", help=".npy file with one [N, N] image or a stack [S, N, N]")
+    parser.add_argument("--apix", type=float, required=True, help="pixel size, Angstrom")
+    parser.add_argument("--twist", type=float, nargs=3, metavar=("MIN", "MAX", "STEP"), required=True)
+    parser.add_argument("--rise", type=float, nargs=3, metavar=("MIN", "MAX", "STEP"), required=True)
+    parser.add_argument("--csym", type=int, nargs="+", default=[1])
+    parser.add_argument("--helical-diameter", type=float, default=None, help="Angstrom (default 0.4 * N * apix)")
+    parser.add_argument("--ball-radius", type=float, default=None, help="Angstrom (default 2 * apix)")
+    parser.add_argument("--rot", type=float, default=0.0)
+    parser.add_argument("--tilt", type=float, default=0.0)
+    parser.add_argument("--psi", type=float, default=0.0)
+    parser.add_argument("--dy", type=float, default=0.0)
+    parser.add_argument("--mask", default=None, help=".npy boolean mask on the fftshifted plane (default: radial band)")
+    parser.add_argument("--no-log", action="store_true", help="correlate |F| instead of log1p|F|")
+    parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--top", type=int, default=10, help="how many best candidates to print per image")
+    parser.add_argument("--out", default=None, help=".npz with scores[S, C, T, R], twists, rises, csyms")
+    return parser
+
+
+def run(args) -> dict:
+    images = np.load(args.image)
+    if images.ndim == 2:
+        images = images[None]
+    n = images.shape[-1]
+    twists = sweep_axis(*args.twist)
+    rises = sweep_axis(*args.rise)
+    mask = np.load(args.mask) if args.mask else None
+    res = sweep(
+        images, twists, rises, tuple(args.csym), apix=args.apix,
+        helical_diameter=args.helical_diameter if args.helical_diameter is not None else 0.4 * n * args.apix,
+        ball_radius=args.ball_radius if args.ball_radius is not None else 2.0 * args.apix,
+        mask=mask, log=not args.no_log, rot=args.rot, tilt=args.tilt, psi=args.psi, dy=args.dy, device=args.device,
+    )
+    report = {"n_candidates": int(len(res.grid)), "n_skipped": int((~res.grid.valid).sum()), "images": []}
+    flat = res.scores.reshape(res.scores.shape[0], -1)
+    for s in range(flat.shape[0]):
+        order = np.argsort(-flat[s], kind="stable")[: args.top]  # score descending, like app.py:2521-2523
+        report["images"].append({
+            "index": s,
+            "best": dict(zip(("twist", "rise", "csym", "score"), res.best[s])),
+            "top": [dict(twist=float(res.grid.params[g, 0]), rise=float(res.grid.params[g, 1]),
+                         csym=int(res.grid.params[g, 2]), score=float(flat[s, g])) for g in order],
+        })
+    if args.out:
+        np.savez_compressed(args.out, scores=res.scores, twists=twists, rises=rises, csyms=np.asarray(args.csym),
+                            params=res.grid.params, valid=res.grid.valid)
+    return report
+
+
+def main(argv=None) -> int:
+    args = add_args(argparse.ArgumentParser(prog="denovo3DBatch", description=__doc__.split("\n\n")[0])).parse_args(argv)
+    json.dump(run(args), sys.stdout, indent=1)
+    sys.stdout.write("\n")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -346,3 +346,27 @@ def test_many_segments_match_single_segment_sweeps():
     mask = O.radial_band_mask(n, n)
     ref = O.sweep_cpu(imgs[69], params[:5, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
     np.testing.assert_allclose(multi[69, :5], ref, rtol=0, atol=SCORE_TOL)
+
+
+def test_c1_workload_and_batch_driver(tmp_path):
+    """BASELINE config 1 (256^2, 40 x 25 grid) through the headless driver: the arg-max is the truth and a
+    strided sample of the 1,000 scores agrees with the oracle."""
+    from helicon_amd import denovo3DBatch as B
+
+    n, apix = 256, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1, seed=0)
+    np.save(tmp_path / "img.npy", img)
+    args = B.add_args(__import__("argparse").ArgumentParser()).parse_args(
+        [str(tmp_path / "img.npy"), "--apix", str(apix), "--twist", "25", "32.8", "0.2", "--rise", "8", "12.8", "0.2",
+         "--out", str(tmp_path / "scores.npz"), "--top", "3"])
+    rep = B.run(args)
+    assert rep["n_candidates"] == 1000 and rep["n_skipped"] == 0
+    best = rep["images"][0]["best"]
+    assert (round(best["twist"], 6), round(best["rise"], 6), best["csym"]) == (29.0, 10.0, 1)
+    out = np.load(tmp_path / "scores.npz")
+    assert out["scores"].shape == (1, 1, 40, 25)
+    pick = np.arange(0, 1000, 67)
+    ref = O.sweep_cpu(img, out["params"][pick, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(out["scores"].reshape(-1)[pick], ref, rtol=0, atol=SCORE_TOL)
+    top = rep["images"][0]["top"]
+    assert top[0]["score"] >= top[1]["score"] >= top[2]["score"]

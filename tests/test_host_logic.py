@@ -95,3 +95,14 @@ def test_product_never_imports_oracle():
     for f in (ROOT / "helicon_amd").rglob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_batch_driver_arguments():
+    import argparse
+
+    from helicon_amd import denovo3DBatch as B
+
+    a = B.add_args(argparse.ArgumentParser()).parse_args(
+        ["x.npy", "--apix", "2", "--twist", "25", "33", "0.2", "--rise", "8", "13", "0.2", "--csym", "1", "3"])
+    assert a.csym == [1, 3] and a.twist == [25.0, 33.0, 0.2] and not a.no_log and a.top == 10
+    assert len(H.sweep_axis(*a.twist)) == 41 and len(H.sweep_axis(*a.rise)) == 26
