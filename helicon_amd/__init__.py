@@ -6,6 +6,5 @@ from .grid import (CandidateGrid, build_grid, layer_line_mask, radial_band_mask,
 from .denovo3D import (SweepEngine, SweepResult, compute_power_spectra, cosine_similarity,
                        cross_correlation_coefficient, process_one_task, simulate_helical_projection, sweep)
 from ._lib import HeliconHipError
-from . import denovo3DBatch  # noqa: F401  (python -m helicon_amd.denovo3DBatch)
 
 __version__ = "0.1.0"
