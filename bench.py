@@ -52,7 +52,7 @@ def usable_cores():
     return min(n, 16)
 
 
-def cpu_baseline_leg(w, sample_per_core=24):
+def cpu_baseline_leg(w, sample_per_core=48):
     """The CPU oracle (NumPy port of the reference path) on this host's cores, bounded sample."""
     from oracle import cpu_baseline
 
