@@ -402,6 +402,8 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
   const float lo = (float)(xa - g.rpx - 1), hi = (float)(xa + 1 + g.rpx + 1);
   const float qxa = (float)(xa - N / 2) * g.apix, qxb = (float)(xa + 1 - N / 2) * g.apix;  // X of utils.py:94-99
   const float rp = (float)g.rpx;
+  int cur = -1;  // slot pair currently gathered in acc_* (T >= 64 path)
+  float acc_ax = 0.f, acc_ay = 0.f, acc_bx = 0.f, acc_by = 0.f;
   for (int base = 0; base < count; base += TL) {
     bool hit = false;
     float2 p = make_float2(0.f, 0.f);
@@ -447,13 +449,26 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
         const float ax = in_a ? px : 0.f, ay = in_a ? py : 0.f;
         const float bx = in_a ? 0.f : px, by = in_a ? 0.f : py;
         if constexpr (T >= 64) {
-          // m0 is wave-uniform: the two slots are addressed with the VGPR index register
-          // (s_set_gpr_idx), 4 indexed adds instead of 32 weighted FMAs
-          const int i0 = __builtin_amdgcn_readfirstlane(m0), i1 = i0 < 7 ? i0 + 1 : 7;
-          r[2 * i0] += ax;
-          r[2 * i0 + 1] += ay;
-          r[2 * i1] += bx;      // bx = by = 0 whenever slot m0 + 1 would be past the image
-          r[2 * i1 + 1] += by;
+          // m0 is wave-uniform.  Consecutive lattice centres mostly fall into the same slot pair
+          // (the row coordinate moves by a few pixels per subunit at small twist), so the four
+          // contributions are gathered in plain registers and only moved into the slot file
+          // r[] — through the VGPR index register (s_set_gpr_idx) — when m0 changes.
+          const int i0 = __builtin_amdgcn_readfirstlane(m0);
+          if (i0 != cur) {
+            if (cur >= 0) {
+              const int j1 = cur < 7 ? cur + 1 : 7;
+              r[2 * cur] += acc_ax;
+              r[2 * cur + 1] += acc_ay;
+              r[2 * j1] += acc_bx;  // zero whenever slot cur + 1 would be past the image
+              r[2 * j1 + 1] += acc_by;
+            }
+            cur = i0;
+            acc_ax = acc_ay = acc_bx = acc_by = 0.f;
+          }
+          acc_ax += ax;
+          acc_ay += ay;
+          acc_bx += bx;
+          acc_by += by;
         } else {
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
@@ -463,6 +478,15 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
           }
         }
       }
+    }
+  }
+  if constexpr (T >= 64) {
+    if (cur >= 0) {
+      const int j1 = cur < 7 ? cur + 1 : 7;
+      r[2 * cur] += acc_ax;
+      r[2 * cur + 1] += acc_ay;
+      r[2 * j1] += acc_bx;
+      r[2 * j1 + 1] += acc_by;
     }
   }
 }
