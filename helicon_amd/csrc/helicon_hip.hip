@@ -405,33 +405,44 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
   int cur = -1;  // slot pair currently gathered in acc_* (T >= 64 path)
   float acc_ax = 0.f, acc_ay = 0.f, acc_bx = 0.f, acc_by = 0.f;
   for (int base = 0; base < count; base += TL) {
+    // every lane prepares one candidate centre: position, row range of its footprint, and the
+    // squared column offsets for this pair; a hit then only broadcasts the prepared values
     bool hit = false;
-    float2 p = make_float2(0.f, 0.f);
+    float pyc = 0.f, pea = 0.f, peb = 0.f;
+    int py0 = 0, py1 = -1;
     const int ci = base + (t & (TL - 1));
     if (ci < count) {
-      p = cent[ci];
+      const float2 p = cent[ci];
+      pyc = p.x;
       const float cx = p.y * g.inv_apix + (float)(N / 2);
       const float cy = p.x * g.inv_apix + (float)(N / 2);
       hit = (cx >= lo) && (cx <= hi) && (cy >= -rp - 1.f) && (cy <= (float)N + rp);
+      py0 = max(0, (int)ceilf(cy - rp));
+      py1 = min(N - 1, (int)floorf(cy + rp));
+      const float dxa = qxa - p.y, dxb = qxb - p.y;
+      // a column outside the footprint gets an offset that underflows the exponential to 0
+      pea = fabsf((float)xa - cx) <= rp ? dxa * dxa : 3.0e38f;
+      peb = fabsf((float)(xa + 1) - cx) <= rp ? dxb * dxb : 3.0e38f;
     }
     unsigned long long todo = (__ballot(hit) >> gbase) & gmask;
     while (todo) {
       const int k = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      float yc, xc;
-      if constexpr (T >= 64) {  // k is wave-uniform: scalar lane read, no LDS round trip
-        yc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), k));
-        xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), k));
+      float yc, ea, eb;
+      int y0, y1;
+      if constexpr (T >= 64) {  // k is wave-uniform: scalar lane reads, no LDS round trip
+        yc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pyc), k));
+        ea = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pea), k));
+        eb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(peb), k));
+        y0 = __builtin_amdgcn_readlane(py0, k);
+        y1 = __builtin_amdgcn_readlane(py1, k);
       } else {
-        yc = __shfl(p.x, gbase + k, 64);
-        xc = __shfl(p.y, gbase + k, 64);
+        yc = __shfl(pyc, gbase + k, 64);
+        ea = __shfl(pea, gbase + k, 64);
+        eb = __shfl(peb, gbase + k, 64);
+        y0 = __shfl(py0, gbase + k, 64);
+        y1 = __shfl(py1, gbase + k, 64);
       }
-      const float cx = xc * g.inv_apix + (float)(N / 2);
-      const float cy = yc * g.inv_apix + (float)(N / 2);
-      const float dxa = qxa - xc, dxb = qxb - xc;
-      const float ea = dxa * dxa, eb = dxb * dxb;
-      const bool cola = fabsf((float)xa - cx) <= rp, colb = fabsf((float)(xa + 1) - cx) <= rp;
-      const int y0 = max(0, (int)ceilf(cy - rp)), y1 = min(N - 1, (int)floorf(cy + rp));
       // Walk the footprint's rows in chunks of at most T rows (one chunk for T = 64, R <= 31):
       // a chunk touches each lane at most once, in register slot m0 or m0 + 1, and m0 is
       // uniform across the group, so the slot is chosen by multiplying with 0/1 weights.
@@ -444,8 +455,8 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
         const float dyv = (float)(y - N / 2) * g.apix - yc;
         const float d2 = dyv * dyv;
         const bool rowok = y <= ye;
-        const float px = (rowok && cola) ? __expf(-(ea + d2) * g.inv_sigma2) : 0.f;
-        const float py = (rowok && colb) ? __expf(-(eb + d2) * g.inv_sigma2) : 0.f;
+        const float px = rowok ? __expf(-(ea + d2) * g.inv_sigma2) : 0.f;
+        const float py = rowok ? __expf(-(eb + d2) * g.inv_sigma2) : 0.f;
         const float ax = in_a ? px : 0.f, ay = in_a ? py : 0.f;
         const float bx = in_a ? 0.f : px, by = in_a ? 0.f : py;
         if constexpr (T >= 64) {
