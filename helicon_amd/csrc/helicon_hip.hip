@@ -2,15 +2,19 @@
 // sweep.  See include/helicon_hip.h for the boundary and DESIGN.md for the data layout.
 //
 // Per candidate (reference semantics in brackets):
-//   K_A  k_first_pass   rasterise the helical lattice of Gaussian balls straight into LDS
-//                       [utils.py:91-106, 153-172], FFT every image COLUMN (along y) with two real
-//                       columns packed into one complex transform, write the half spectrum
-//                       H[ky in 0..N/2-1][x] (row 0 packs ky=0 and ky=N/2) to HBM.
-//   K_B  k_second_pass  FFT every row of H along x -> F[ky][kx] on the half plane, then
-//                       a=|F|, q=log1p(a) [transforms.py:805-810] and the three masked moments
-//                       sum w q, sum w q^2, sum w (E-Ebar) q with Hermitian weights w in {0,1,2},
-//                       wave-shuffle + LDS reduced.
-//   K_C  k_finalize     Pearson coefficient from the moments [analysis.py:793-799].
+//   K_A  k_first_pass   rasterise the helical lattice of Gaussian balls straight into the FFT input
+//                       registers [utils.py:91-106, 153-172], FFT every image COLUMN (along y) with
+//                       two real columns packed into one complex transform, write the half spectrum
+//                       H (N/2 x N complex, row 0 packs ky=0 and ky=N/2) in 128-byte lines of
+//                       8 ky x 1 column pair.
+//   K_B  k_second_pass  transpose 8-row blocks of H through LDS, FFT every row along x ->
+//                       F[ky][kx] on the half plane, then a=|F|, q=log1p(a) [transforms.py:805-810]
+//                       and the three masked moments sum w q, sum w q^2, sum w (E-Ebar) q with
+//                       Hermitian weights w in {0,1,2}, wave-shuffle + LDS reduced.
+//   K_C  finalize       Pearson coefficient from the moments [analysis.py:793-799] (an extra
+//                       workgroup layer of the next K_A launch, or k_finalize).
+//   several segments:   K_B keeps q, k_segment_corr contracts it with all segments' centred
+//                       spectra on the f32 matrix cores, k_finalize_segments scores S x G.
 // Everything is wave64 code: an N-point FFT is owned by N/8 lanes holding 8 points each
 // (one wavefront for N = 512), Stockham radix-8/4/2 stages exchange through LDS.
 #include <hip/hip_runtime.h>
@@ -26,9 +30,6 @@
 #include "../../include/helicon_hip.h"
 
 // Tuning knobs (compile-time; defaults are the measured best)
-#ifndef HH_KB_PREFETCH
-#define HH_KB_PREFETCH 0   // K_B: load row r+1 while row r is transformed
-#endif
 #ifndef HH_ABLATE
 #define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads,
                            // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads
