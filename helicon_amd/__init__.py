@@ -3,7 +3,7 @@ Python signatures.  Hand-written gfx950 kernels in ``csrc/``, reached through th
 ``include/helicon_hip.h``; importing this package does not touch the GPU."""
 from .grid import (CandidateGrid, build_grid, layer_line_mask, radial_band_mask, set_to_periodic_range,
                    shard_bounds, sweep_axis)
-from .denovo3D import (SweepEngine, SweepResult, compute_power_spectra, cosine_similarity,
+from .denovo3D import (SweepEngine, SweepResult, apply_helical_symmetry, compute_power_spectra, cosine_similarity,
                        cross_correlation_coefficient, process_one_task, simulate_helical_projection, sweep)
 from ._lib import HeliconHipError
 

@@ -1014,6 +1014,67 @@ __global__ void k_pair_sums(const T* __restrict__ x, const T* __restrict__ y, in
 }
 
 // ------------------------------------------------------------------------------------------
+// apply_helical_symmetry (reference: lib/transforms.py:58-165): every output voxel gathers, for
+// each helical repeat hi in [-hmax, hmax] and cyclic copy ci, the trilinearly interpolated input
+// at the symmetry-related position and averages.  One thread per output voxel; coordinates and
+// weights in float64 and the running sum rounded to float32 after every term, in the reference's
+// (hi, ci) order, with FP contraction off, so the result matches NumPy bit for bit up to the
+// last-ulp difference of the host's cos/sin.
+// ------------------------------------------------------------------------------------------
+struct SymArgs {
+  const float* data;   // [nz0][ny0][nx0]
+  float* out;          // [oz][oy][ox]
+  const double* rot;   // [(2 hmax + 1) * csym][2] = cos, sin of twist * hi + 360 ci / csym
+  int nz0, ny0, nx0;   // input volume
+  int nz, ny, nx;      // work volume = element-wise max of input and requested size
+  int cz, cy, cx;      // crop origin of the output inside the work volume
+  int oz, oy, ox;      // output size
+  int hmax, csym, z0, z1;
+  double apix, new_apix, rise;
+};
+
+__global__ __launch_bounds__(256) void k_apply_helical_symmetry(SymArgs a) {
+#pragma clang fp contract(off)
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.oz * a.oy * a.ox;
+  if (idx >= total) return;
+  const int io = (int)(idx % a.ox), jo = (int)((idx / a.ox) % a.oy), ko = (int)(idx / ((size_t)a.ox * a.oy));
+  const int k = ko + a.cz, j = jo + a.cy, i = io + a.cx;
+  const double jj = (double)(j - a.ny / 2);   // integer centre (transforms.py:117)
+  const double ii = (double)i - (double)a.nx / 2.0;  // float centre: the reference's nx / 2
+  float acc = 0.f, cnt = 0.f;
+  for (int hi = -a.hmax; hi <= a.hmax; ++hi) {
+    const double k2 = ((double)(k - a.nz / 2) * a.new_apix + (double)hi * a.rise) / a.apix + (double)(a.nz0 / 2);
+    if (k2 < (double)a.z0 || k2 >= (double)a.z1) continue;
+    const int kf = (int)floor(k2), kc = (int)ceil(k2);
+    const double wk = k2 - (double)kf;
+    const float* const d0 = a.data + (size_t)kf * a.ny0 * a.nx0;
+    const float* const d1 = a.data + (size_t)kc * a.ny0 * a.nx0;
+    for (int ci = 0; ci < a.csym; ++ci) {
+      const double c = a.rot[2 * ((size_t)(hi + a.hmax) * a.csym + ci)];
+      const double s = a.rot[2 * ((size_t)(hi + a.hmax) * a.csym + ci) + 1];
+      const double j2 = (c * jj + s * ii) * a.new_apix / a.apix + (double)(a.ny0 / 2);
+      const double i2 = ((-s) * jj + c * ii) * a.new_apix / a.apix + (double)(a.nx0 / 2);
+      const double j2f = floor(j2), i2f = floor(i2);
+      if (j2f < 0.0 || j2f >= (double)(a.ny0 - 1) || i2f < 0.0 || i2f >= (double)(a.nx0 - 1)) continue;
+      const int jf = (int)j2f, jc = (int)ceil(j2), i_f = (int)i2f, ic = (int)ceil(i2);
+      const double wj = j2 - j2f, wi = i2 - i2f;
+      double v = (1 - wk) * (1 - wj) * (1 - wi) * (double)d0[(size_t)jf * a.nx0 + i_f];
+      v = v + (1 - wk) * (1 - wj) * wi * (double)d0[(size_t)jf * a.nx0 + ic];
+      v = v + (1 - wk) * wj * (1 - wi) * (double)d0[(size_t)jc * a.nx0 + i_f];
+      v = v + (1 - wk) * wj * wi * (double)d0[(size_t)jc * a.nx0 + ic];
+      v = v + wk * (1 - wj) * (1 - wi) * (double)d1[(size_t)jf * a.nx0 + i_f];
+      v = v + wk * (1 - wj) * wi * (double)d1[(size_t)jf * a.nx0 + ic];
+      v = v + wk * wj * (1 - wi) * (double)d1[(size_t)jc * a.nx0 + i_f];
+      v = v + wk * wj * wi * (double)d1[(size_t)jc * a.nx0 + ic];
+      acc = (float)((double)acc + v);  // data_work is float32 in the reference (transforms.py:81-83, 133)
+      cnt += 1.0f;
+    }
+  }
+  a.out[idx] = cnt > 0.f ? acc / cnt : acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // traffic-counter calibration (profiling aid): the sweep's two global access shapes on a known
 // byte count, so rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes for THESE shapes
 // (MI355X_MICROARCH.md, HBM: FETCH_SIZE is only calibrated for 16-B-per-lane streams)
@@ -1765,6 +1826,92 @@ int hh_cross_correlation(hh_ctx* c, const float* a, const float* b, int64_t n, d
 int hh_cross_correlation_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return pearson(c, a, b, n, out); }
 int hh_cosine_similarity(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
 int hh_cosine_similarity_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
+
+int hh_apply_helical_symmetry(int device, const float* data, const int32_t in_shape[3], double apix,
+                              double twist_degree, double rise_angstrom, int csym, double fraction,
+                              const int32_t new_size[3], double new_apix, float* out, int32_t out_shape[3],
+                              double* kernel_ms) {
+  if (!data || !in_shape || !new_size || !out_shape)
+    return fail(nullptr, HH_ERR_ARG, "hh_apply_helical_symmetry: NULL argument");
+  const int nz0 = in_shape[0], ny0 = in_shape[1], nx0 = in_shape[2];
+  const int nz1 = new_size[0], ny1 = new_size[1], nx1 = new_size[2];
+  if (nz0 < 2 || ny0 < 2 || nx0 < 2 || nz1 < 1 || ny1 < 1 || nx1 < 1 || csym < 1 || !(apix > 0) || !(new_apix > 0) ||
+      !(rise_angstrom > 0))
+    return fail(nullptr, HH_ERR_ARG, "hh_apply_helical_symmetry: bad shape or parameter");
+  SymArgs a{};
+  a.nz0 = nz0; a.ny0 = ny0; a.nx0 = nx0;
+  const bool same = nz0 == nz1 && ny0 == ny1 && nx0 == nx1;
+  a.nz = std::max(nz0, nz1); a.ny = std::max(ny0, ny1); a.nx = std::max(nx0, nx1);
+  if (same || (a.nz == nz1 && a.ny == ny1 && a.nx == nx1)) {  // transforms.py:158: no crop
+    a.cz = a.cy = a.cx = 0;
+    a.oz = a.nz; a.oy = a.ny; a.ox = a.nx;
+  } else {  // Python slice [n//2 - n1//2 : n//2 + n1//2] on every axis
+    a.cz = std::max(0, a.nz / 2 - nz1 / 2); a.oz = std::min(a.nz, a.nz / 2 + nz1 / 2) - a.cz;
+    a.cy = std::max(0, a.ny / 2 - ny1 / 2); a.oy = std::min(a.ny, a.ny / 2 + ny1 / 2) - a.cy;
+    a.cx = std::max(0, a.nx / 2 - nx1 / 2); a.ox = std::min(a.nx, a.nx / 2 + nx1 / 2) - a.cx;
+  }
+  out_shape[0] = a.oz; out_shape[1] = a.oy; out_shape[2] = a.ox;
+  if (!out) return HH_OK;  // shape query
+  a.apix = apix; a.new_apix = new_apix; a.rise = rise_angstrom; a.csym = csym;
+  a.hmax = std::max(1, (int)((double)a.nz * new_apix / rise_angstrom));  // transforms.py:88
+  // z range of the input that carries density (transforms.py:92-99)
+  std::vector<double> prof(nz0, 0.0);
+  for (int k = 0; k < nz0; ++k) {
+    double acc = 0;
+    const float* p = data + (size_t)k * ny0 * nx0;
+    for (size_t q = 0; q < (size_t)ny0 * nx0; ++q) acc += p[q];
+    prof[k] = acc;
+  }
+  const double thr = 0.01 * *std::max_element(prof.begin(), prof.end());
+  int z0 = -1, z1 = -1;
+  for (int k = 0; k < nz0; ++k)
+    if (prof[k] > thr) { if (z0 < 0) z0 = k; z1 = k; }
+  if (z0 < 0) return fail(nullptr, HH_ERR_ARG, "hh_apply_helical_symmetry: the volume has no density above 1 % of its peak slice");
+  const int zmid = (z0 + z1) / 2 + (z0 + z1) % 2;
+  const int half = (int)((double)nz0 * fraction + 0.5) / 2;
+  a.z0 = std::max(z0, zmid - half);
+  a.z1 = std::min(z1, zmid + half);
+  std::vector<double> rot((size_t)(2 * a.hmax + 1) * csym * 2);
+  for (int hi = -a.hmax; hi <= a.hmax; ++hi)
+    for (int ci = 0; ci < csym; ++ci) {
+      const double r = (twist_degree * hi + 360.0 * ci / csym) * (M_PI / 180.0);  // np.deg2rad
+      rot[2 * ((size_t)(hi + a.hmax) * csym + ci)] = std::cos(r);
+      rot[2 * ((size_t)(hi + a.hmax) * csym + ci) + 1] = std::sin(r);
+    }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, HH_ERR_HIP, "hh_apply_helical_symmetry: no such HIP device (no CPU fallback)");
+  HH_HIP(nullptr, hipSetDevice(device));
+  const size_t n_in = (size_t)nz0 * ny0 * nx0, n_out = (size_t)a.oz * a.oy * a.ox;
+  float *d_in = nullptr, *d_out = nullptr;
+  double* d_rot = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&d_in, n_in * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_out, n_out * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_rot, rot.size() * sizeof(double));
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemcpy(d_in, data, n_in * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_rot, rot.data(), rot.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    a.data = d_in; a.out = d_out; a.rot = d_rot;
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_apply_helical_symmetry, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, nullptr, a);
+    (void)hipEventRecord(e1, nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && kernel_ms) {
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, e0, e1);
+    *kernel_ms = ms;
+  }
+  (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_rot);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_apply_helical_symmetry: ") + hipGetErrorString(e));
+  return HH_OK;
+}
 
 int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
   if (!c || bytes <= 0 || (mode != 0 && mode != 1)) return fail(c, HH_ERR_ARG, "hh_calibrate_traffic: bad argument");

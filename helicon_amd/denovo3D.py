@@ -32,6 +32,7 @@ __all__ = [
     "cross_correlation_coefficient",
     "cosine_similarity",
     "process_one_task",
+    "apply_helical_symmetry",
     "units_to_cylindrical",
 ]
 
@@ -304,6 +305,30 @@ def cross_correlation_coefficient(a, b, *, device=0):
 def cosine_similarity(a, b, *, device=0):
     """analysis.py:802-821."""
     return _engine(64, device).cosine_similarity(a, b)
+
+
+def apply_helical_symmetry(data, apix, twist_degree, rise_angstrom, csym=1, fraction=1.0, new_size=None,
+                           new_apix=None, cpu=1, *, device=0, return_kernel_ms=False):
+    """transforms.py:58-74 (same positional signature; ``cpu`` is accepted and ignored).  ``new_size=None``
+    means "same size" (the reference cannot unpack ``None``, transforms.py:78-79)."""
+    vol = np.ascontiguousarray(data, dtype=np.float32)
+    if vol.ndim != 3:
+        raise ValueError("data must be a 3D volume (nz, ny, nx)")
+    if new_apix is None:
+        new_apix = apix
+    if new_size is None:
+        new_size = vol.shape
+    L = _lib.lib()
+    in_shape = (C.c_int32 * 3)(*vol.shape)
+    want = (C.c_int32 * 3)(*[int(v) for v in new_size])
+    out_shape = (C.c_int32 * 3)()
+    args = (int(device), _ptr(vol, C.c_float), in_shape, float(apix), float(twist_degree), float(rise_angstrom),
+            int(csym), float(fraction), want, float(new_apix))
+    _lib.check(L.hh_apply_helical_symmetry(*args, None, out_shape, None), None)
+    out = np.empty(tuple(out_shape), dtype=np.float32)
+    ms = C.c_double(0.0)
+    _lib.check(L.hh_apply_helical_symmetry(*args, _ptr(out, C.c_float), out_shape, C.byref(ms)), None)
+    return (out, ms.value) if return_kernel_ms else out
 
 
 # ------------------------------------------------------------------------------------------

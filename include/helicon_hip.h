@@ -11,6 +11,7 @@
  *   hh_power_spectrum      lib/transforms.py:771-820          compute_power_spectra (defaults)
  *   hh_cross_correlation   lib/analysis.py:777-799            cross_correlation_coefficient
  *   hh_cosine_similarity   lib/analysis.py:802-821            cosine_similarity
+ *   hh_apply_helical_symmetry  lib/transforms.py:58-165       apply_helical_symmetry
  *   hh_set_reference +     webApps/denovo3D/app.py:2455-2523  reconstruction_task (the pool over
  *   hh_sweep[_device]                                         candidates) scoring each candidate by
  *                                                             cc(ref[mask], pwr[mask])
@@ -130,6 +131,18 @@ int hh_cross_correlation(hh_ctx* ctx, const float* a, const float* b, int64_t n,
 int hh_cosine_similarity(hh_ctx* ctx, const float* a, const float* b, int64_t n, double* out);
 int hh_cross_correlation_f64(hh_ctx* ctx, const double* a, const double* b, int64_t n, double* out);
 int hh_cosine_similarity_f64(hh_ctx* ctx, const double* a, const double* b, int64_t n, double* out);
+
+/* Helical symmetrisation of a 3-D map (transforms.py:58-165): data is host float32
+ * [in_shape[0]][in_shape[1]][in_shape[2]] (z, y, x); new_size / new_apix as in the reference (pass the
+ * input's own shape / apix for "unchanged").  out receives out_shape[0..2] float32 voxels — the
+ * requested size, or its even-cropped version when the reference's final slice applies
+ * (transforms.py:158-164); call with out == NULL to query out_shape only.  kernel_ms (may be NULL)
+ * returns the device time of the gather kernel.  Context-free: errors are read with
+ * hh_last_error(NULL). */
+int hh_apply_helical_symmetry(int device, const float* data, const int32_t in_shape[3], double apix,
+                              double twist_degree, double rise_angstrom, int csym, double fraction,
+                              const int32_t new_size[3], double new_apix, float* out, int32_t out_shape[3],
+                              double* kernel_ms);
 
 int hh_synchronize(hh_ctx* ctx);
 

@@ -20,7 +20,7 @@ from pathlib import Path
 import numpy as np
 
 import helicon  # the reference
-from helicon.lib import analysis, filters, angular
+from helicon.lib import analysis, filters, angular, transforms
 from helicon.webApps.denovo3D import utils
 
 OUT = Path(__file__).resolve().parent
@@ -145,12 +145,42 @@ def g6_filters():
     np.savez_compressed(OUT / "g6_filters.npz", **arrs)
 
 
+def _blob_volume(shape, seed):
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    Z, Y, X = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    vol = np.zeros(shape)
+    for _ in range(12):
+        cz, cy, cx = rng.uniform(0.2, 0.8, 3) * np.asarray(shape)
+        vol += rng.uniform(0.5, 1.5) * np.exp(-((Z - cz) ** 2 + (Y - cy) ** 2 + (X - cx) ** 2) / rng.uniform(3, 9))
+    return vol.astype(np.float32)
+
+
+def g7_helical_sym():
+    """apply_helical_symmetry (transforms.py:58-165; pure-Python fallback of the numba kernel)."""
+    cases = [
+        # (shape, apix, twist, rise, csym, fraction, new_size, new_apix)
+        ((20, 16, 16), 2.0, 30.0, 8.0, 1, 1.0, (20, 16, 16), None),
+        ((18, 16, 14), 2.0, -41.5, 6.5, 3, 0.5, (26, 18, 18), 2.5),
+        ((24, 20, 20), 1.5, 12.0, 4.75, 2, 1.0, (16, 14, 14), 1.5),
+    ]
+    arrs = {"n_cases": np.asarray([len(cases)])}
+    for k, (shape, apix, tw, rs, cs, fr, ns, na) in enumerate(cases):
+        vol = _blob_volume(shape, 70 + k)
+        out = transforms.apply_helical_symmetry(vol, apix, tw, rs, csym=cs, fraction=fr, new_size=ns, new_apix=na, cpu=1)
+        arrs[f"case{k}_in"] = vol
+        arrs[f"case{k}_args"] = np.asarray([apix, tw, rs, cs, fr, *ns, -1.0 if na is None else na], dtype=np.float64)
+        arrs[f"case{k}_out"] = np.asarray(out)
+    np.savez_compressed(OUT / "g7_helical_sym.npz", **arrs)
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     g1_simulate()
     g2_scores()
     g3_composed()
     g6_filters()
+    g7_helical_sym()
     (OUT / "VERSIONS.json").write_text(json.dumps(versions(), indent=1) + "\n")
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -370,3 +370,31 @@ def test_c1_workload_and_batch_driver(tmp_path):
     np.testing.assert_allclose(out["scores"].reshape(-1)[pick], ref, rtol=0, atol=SCORE_TOL)
     top = rep["images"][0]["top"]
     assert top[0]["score"] >= top[1]["score"] >= top[2]["score"]
+
+
+# ---------------------------------------------------------------------------- apply_helical_symmetry
+def test_apply_helical_symmetry_matches_golden_and_oracle(golden_dir):
+    from oracle import symmetrize as S
+
+    g = np.load(golden_dir / "g7_helical_sym.npz")
+    for k in range(int(g["n_cases"][0])):
+        apix, tw, rs, cs, fr, n1, n2, n3, na = g[f"case{k}_args"]
+        out = H.apply_helical_symmetry(g[f"case{k}_in"], apix, tw, rs, csym=int(cs), fraction=fr,
+                                       new_size=(int(n1), int(n2), int(n3)), new_apix=None if na < 0 else na)
+        ref = g[f"case{k}_out"]
+        assert out.shape == ref.shape and out.dtype == np.float32
+        # float64 coordinates / float32 running sum exactly as the reference; only the host's cos/sin can
+        # differ from NumPy's in the last ulp
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6, err_msg=f"case {k}")
+    rng = np.random.default_rng(3)
+    vol = rng.random((40, 32, 30)).astype(np.float32)
+    vol[:6] = 0
+    vol[-5:] = 0
+    for kw in (dict(csym=2, new_size=(48, 32, 32), new_apix=1.2), dict(csym=1, fraction=0.6, new_size=(40, 32, 30)),
+               dict(csym=5, new_size=(30, 25, 25), new_apix=1.0)):
+        out = H.apply_helical_symmetry(vol, 1.0, 23.7, 4.75, **kw)
+        ref = S.apply_helical_symmetry(vol, 1.0, 23.7, 4.75, **kw)
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        H.apply_helical_symmetry(vol[0], 1.0, 23.7, 4.75)
