@@ -9,7 +9,8 @@ descending, app.py:2521-2523) this driver reproduces without the Shiny UI.
     python -m helicon_amd.denovo3DBatch image.npy --apix 2.0 --twist 25 33 0.2 --rise 8 13 0.2 \\
            --csym 1 --out scores.npz [--mask mask.npy] [--no-log] [--device 0] [--top 10]
 
-Images are ``.npy`` arrays (``[N, N]`` or ``[S, N, N]``; square, side a power of two in 32…1024).
+Images are ``.npy`` arrays or MRC files/stacks (``[N, N]`` or ``[S, N, N]``; square, side a power of two
+in 32…1024); ``--index`` picks slices of a stack like ``read_image_2d`` (io_mrc.py:71-100).
 """
 from __future__ import annotations
 
@@ -24,8 +25,9 @@ from .grid import sweep_axis
 
 
 def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
-    parser.add_argument("image", help=".npy file with one [N, N] image or a stack [S, N, N]")
-    parser.add_argument("--apix", type=float, required=True, help="pixel size, Angstrom")
+    parser.add_argument("image", help=".npy / .mrc / .mrcs file with one [N, N] image or a stack [S, N, N]")
+    parser.add_argument("--index", type=int, nargs="*", default=None, help="slices of the stack to use (default: all)")
+    parser.add_argument("--apix", type=float, default=None, help="pixel size, Angstrom (default: the MRC header's)")
     parser.add_argument("--twist", type=float, nargs=3, metavar=("MIN", "MAX", "STEP"), required=True)
     parser.add_argument("--rise", type=float, nargs=3, metavar=("MIN", "MAX", "STEP"), required=True)
     parser.add_argument("--csym", type=int, nargs="+", default=[1])
@@ -44,9 +46,21 @@ def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
 
 
 def run(args) -> dict:
-    images = np.load(args.image)
+    if str(args.image).lower().endswith((".mrc", ".mrcs", ".map")):
+        from .mrc import read_mrc
+
+        images, header_apix = read_mrc(args.image)
+        if args.apix is None:
+            args.apix = header_apix
+    else:
+        images = np.load(args.image)
+    if not args.apix or args.apix <= 0:
+        raise SystemExit("--apix is required (the input carries no pixel size)")
     if images.ndim == 2:
         images = images[None]
+    if args.index:
+        images = images[np.asarray(args.index)]
+    images = np.ascontiguousarray(images, dtype=np.float32)
     n = images.shape[-1]
     twists = sweep_axis(*args.twist)
     rises = sweep_axis(*args.rise)

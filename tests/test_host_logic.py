@@ -106,3 +106,33 @@ def test_batch_driver_arguments():
         ["x.npy", "--apix", "2", "--twist", "25", "33", "0.2", "--rise", "8", "13", "0.2", "--csym", "1", "3"])
     assert a.csym == [1, 3] and a.twist == [25.0, 33.0, 0.2] and not a.no_log and a.top == 10
     assert len(H.sweep_axis(*a.twist)) == 41 and len(H.sweep_axis(*a.rise)) == 26
+
+
+def test_mrc_round_trip_and_reader_errors(tmp_path):
+    from helicon_amd import mrc
+
+    rng = np.random.default_rng(0)
+    stack = rng.normal(size=(3, 8, 12)).astype(np.float32)
+    mrc.write_mrc(tmp_path / "s.mrcs", stack, apix=1.25)
+    data, apix = mrc.read_mrc(tmp_path / "s.mrcs")
+    assert data.shape == (3, 8, 12) and apix == pytest.approx(1.25)
+    np.testing.assert_array_equal(np.asarray(data), stack)
+    assert mrc.image_shape(tmp_path / "s.mrcs") == (12, 8, 3)
+    np.testing.assert_array_equal(mrc.read_image_2d(tmp_path / "s.mrcs", 2), stack[2])
+    with pytest.raises(OSError):
+        mrc.read_image_2d(tmp_path / "s.mrcs", 3)
+    with pytest.raises(OSError):
+        mrc.read_image_2d(tmp_path / "missing.mrc", 0)
+    # big-endian int16 file with an extended header
+    import struct
+    hdr = bytearray(1024)
+    struct.pack_into(">4i", hdr, 0, 4, 2, 1, 1)
+    struct.pack_into(">3i", hdr, 28, 4, 2, 1)
+    struct.pack_into(">3f", hdr, 40, 8.0, 4.0, 2.0)
+    struct.pack_into(">i", hdr, 92, 16)
+    hdr[212:216] = b"\x11\x11\x00\x00"
+    vals = np.arange(8, dtype=">i2")
+    (tmp_path / "b.mrc").write_bytes(bytes(hdr) + b"\0" * 16 + vals.tobytes())
+    data, apix = mrc.read_mrc(tmp_path / "b.mrc")
+    assert apix == pytest.approx(2.0)
+    np.testing.assert_array_equal(np.asarray(data), np.arange(8).reshape(1, 2, 4))
