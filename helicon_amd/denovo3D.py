@@ -393,8 +393,10 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
     apix2d, twist, rise, csym, tilt, psi, dy))``.  ``algorithm`` may carry ``helical_diameter``,
     ``ball_radius``, ``mask`` and ``log``; image preparation options of the reference that need
     scikit-image (denoise, horizontalize, rescaling) are rejected."""
-    if data is None:
-        raise NotImplementedError("reading images from disk (mrcfile) is outside the accelerated path")
+    if data is None:  # pipeline.py:211-212
+        from .mrc import read_image_2d
+
+        data = read_image_2d(imageFile, imageIndex)
     data = np.asarray(data)
     if np.std(data) == 0:
         return None
