@@ -398,3 +398,22 @@ def test_apply_helical_symmetry_matches_golden_and_oracle(golden_dir):
         np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)
     with pytest.raises(ValueError):
         H.apply_helical_symmetry(vol[0], 1.0, 23.7, 4.75)
+
+
+def test_c2_c3_random_candidates_match_oracle():
+    """512^2 (BASELINE configs 2/3): 18 candidates drawn from the whole 400 x 250 grid with Csym 1..6 against
+    the oracle, on the noisy C2 image."""
+    n, apix = 512, 1.0
+    img, d, br = _noisy_helix(n, apix, 1.20, 4.75, 1, seed=0)
+    rng = np.random.default_rng(42)
+    tw = np.round(0.01 * rng.integers(1, 401, 18), 6)
+    rs = 4.0 + 0.005 * rng.integers(0, 250, 18)
+    cs = np.array([1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 6], dtype=float)
+    params = np.stack([tw, rs, cs, np.zeros(18)], axis=1)
+    with H.SweepEngine(n) as eng:
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        eng.set_reference(img)
+        got = eng.sweep(params)[0]
+    ref = O.sweep_cpu(img, params[:, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=SCORE_TOL)
+    assert np.abs(got - ref).max() < 2e-5  # what the fp32 path actually achieves at this size
