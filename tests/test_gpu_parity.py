@@ -417,3 +417,40 @@ def test_c2_c3_random_candidates_match_oracle():
     ref = O.sweep_cpu(img, params[:, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
     np.testing.assert_allclose(got, ref, rtol=0, atol=SCORE_TOL)
     assert np.abs(got - ref).max() < 2e-5  # what the fp32 path actually achieves at this size
+
+
+def test_seeded_geometry_fuzz_against_oracle():
+    """40 seeded random geometries at N = 32 / 64 / 128: ball radii from sub-pixel-ish to footprints that span
+    several row chunks, helices that clip at the image edge, tilt / psi / dy, Csym up to 7, tiny and huge rises,
+    unusual masks.  Simulated image and scores must match the oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        n = int(rng.choice([32, 64, 128], p=[0.4, 0.4, 0.2]))
+        apix = float(rng.choice([1.0, 2.0, 3.3]))
+        br = float(rng.uniform(0.8, 4.5) * apix) if case % 5 else float(rng.uniform(5.0, 7.5) * apix)
+        d = float(rng.uniform(0.1, 0.97) * (0.99 * n * apix - br))
+        tilt = float(rng.choice([0.0, 0.0, rng.uniform(-8, 8)]))
+        psi = float(rng.choice([0.0, 0.0, rng.uniform(-12, 12), 85.0]))
+        dy = float(rng.choice([0.0, rng.uniform(-0.2, 0.2) * n * apix]))
+        rot = float(rng.choice([0.0, rng.uniform(-180, 180)]))
+        csym = int(rng.integers(1, 8))
+        twist = float(rng.uniform(-179, 179))
+        rise = float(rng.choice([rng.uniform(1.0, 30.0), rng.uniform(0.3, 1.0), n * apix * 0.45]))
+        kw = dict(tilt=tilt, psi=psi, dy=dy)
+        tag = f"case {case}: n={n} apix={apix} br={br:.2f} d={d:.1f} tw={twist:.2f} rise={rise:.3f} c={csym} rot={rot:.1f} {kw}"
+        sim = H.simulate_helical_projection(1, twist, rise, csym, d, br, 0, 0, n, n, apix, rot=rot, **kw)
+        ref = O.simulate_helical_projection(1, twist, rise, csym, d, br, 0, 0, n, n, apix, rot=rot, **kw)
+        scale = max(1.0, float(ref.max()))
+        np.testing.assert_allclose(sim, ref, rtol=0, atol=2e-5 * scale, err_msg=tag)
+        img = (ref + rng.normal(0, 0.3 * ref.std() + 1e-3, ref.shape)).astype(np.float32)
+        mask = O.radial_band_mask(n, n) if case % 3 else (rng.random((n, n)) < 0.4)
+        params = np.array([[twist, rise, csym, rot], [twist + 0.7, rise * 1.03, csym, rot],
+                           [-twist, rise, max(1, csym - 1), rot]])
+        with H.SweepEngine(n, max_batch=2) as eng:
+            eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, **kw)
+            eng.set_reference(img, mask, log=bool(case % 2))
+            got = eng.sweep(params)[0]
+        want = np.array([O.score_candidate(O.reference_spectrum(img, apix, log=bool(case % 2)), mask, p[0], p[1], p[2],
+                                           apix=apix, helical_diameter=d, ball_radius=br, log=bool(case % 2),
+                                           rot=p[3], **kw) for p in params])
+        np.testing.assert_allclose(got, want, rtol=0, atol=5e-4, err_msg=tag)
