@@ -40,6 +40,9 @@
 #ifndef HH_KB_TWLDS
 #define HH_KB_TWLDS 0      // K_B: twiddles from a per-workgroup LDS table instead of registers
 #endif
+#ifndef HH_KA_FPW_BIG
+#define HH_KA_FPW_BIG 4      // K_A: transforms per workgroup and tile when a transform spans two wavefronts (N = 1024)
+#endif
 #ifndef HH_KA_BAND
 #define HH_KA_BAND 64       // K_A: image columns per workgroup (N >= 256)
 #endif
@@ -374,7 +377,7 @@ constexpr int MODE_RASTER = 0, MODE_IMAGE = 1, MODE_RASTER_OUT = 2;  // 2: also 
 template <int N>
 struct KA {
   static constexpr int T = N / 8;            // lanes per FFT
-  static constexpr int FPW = 8;              // FFTs per workgroup and tile
+  static constexpr int FPW = T > 64 ? HH_KA_FPW_BIG : 8;  // FFTs per workgroup and tile
   static constexpr int COLS = 2 * FPW;       // image columns per tile
   static constexpr int THREADS = FPW * T;    // == N
   static constexpr int NQ = N >= 256 ? (N / HH_KA_BAND > 0 ? N / HH_KA_BAND : 1) : 1;  // workgroups per candidate
