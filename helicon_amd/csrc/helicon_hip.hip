@@ -406,6 +406,7 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
   const float lo = (float)(xa - g.rpx - 1), hi = (float)(xa + 1 + g.rpx + 1);
   const float qxa = (float)(xa - N / 2) * g.apix, qxb = (float)(xa + 1 - N / 2) * g.apix;  // X of utils.py:94-99
   const float rp = (float)g.rpx;
+  const float k2 = g.inv_sigma2 * 1.44269504088896341f;
   int cur = -1;  // slot pair currently gathered in acc_* (T >= 64 path)
   float acc_ax = 0.f, acc_ay = 0.f, acc_bx = 0.f, acc_by = 0.f;
   for (int base = 0; base < count; base += TL) {
@@ -425,8 +426,8 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
       py1 = min(N - 1, (int)floorf(cy + rp));
       const float dxa = qxa - p.y, dxb = qxb - p.y;
       // a column outside the footprint gets an offset that underflows the exponential to 0
-      pea = fabsf((float)xa - cx) <= rp ? dxa * dxa : 3.0e38f;
-      peb = fabsf((float)(xa + 1) - cx) <= rp ? dxb * dxb : 3.0e38f;
+      pea = fabsf((float)xa - cx) <= rp ? dxa * dxa * k2 : 3.0e38f;
+      peb = fabsf((float)(xa + 1) - cx) <= rp ? dxb * dxb * k2 : 3.0e38f;
     }
     unsigned long long todo = (__ballot(hit) >> gbase) & gmask;
     while (todo) {
@@ -459,8 +460,9 @@ __device__ __forceinline__ void raster_pair(float (&r)[16], const float2* cent, 
         const float dyv = (float)(y - N / 2) * g.apix - yc;
         const float d2 = dyv * dyv;
         const bool rowok = y <= ye;
-        const float px = rowok ? __expf(-(ea + d2) * g.inv_sigma2) : 0.f;
-        const float py = rowok ? __expf(-(eb + d2) * g.inv_sigma2) : 0.f;
+        // exp(-(dx^2 + dy^2) / sigma^2) = 2^-(dx^2 k2 + dy^2 k2), k2 = log2(e) / sigma^2
+        const float px = rowok ? __builtin_amdgcn_exp2f(fmaf(d2, -k2, -ea)) : 0.f;
+        const float py = rowok ? __builtin_amdgcn_exp2f(fmaf(d2, -k2, -eb)) : 0.f;
         const float ax = in_a ? px : 0.f, ay = in_a ? py : 0.f;
         const float bx = in_a ? 0.f : px, by = in_a ? 0.f : py;
         if constexpr (T >= 64) {
