@@ -35,7 +35,7 @@
                            // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads
 #endif
 #ifndef HH_KA_WPS
-#define HH_KA_WPS 6        // K_A: waves per SIMD the register allocator must leave room for (3 workgroups per CU)
+#define HH_KA_WPS 8        // K_A: waves per SIMD the register allocator must leave room for (4 workgroups per CU)
 #endif
 #ifndef HH_KB_TWLDS
 #define HH_KB_TWLDS 0      // K_B: twiddles from a per-workgroup LDS table instead of registers
@@ -64,10 +64,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-
-// LDS index padding: one extra complex slot every 8 breaks the power-of-two strides of the
-// Stockham scatter (stride 8 / 64 complex) across the 32/64 LDS banks.
-__host__ __device__ constexpr int lds_pad(int a) { return a + (a >> 3); }
 
 // Synchronise the T lanes that own one transform.  Up to 64 lanes live in one wavefront, whose
 // LDS instructions execute in program order, so only the compiler has to be fenced; wider groups
@@ -128,12 +124,22 @@ template <> struct Plan<512>  { static constexpr int n = 3; static constexpr int
 template <> struct Plan<1024> { static constexpr int n = 4; static constexpr int r0 = 8, r1 = 8, r2 = 8, r3 = 2; };
 
 constexpr int tw_count(int r) { return r > 1 ? 8 - 8 / r : 0; }  // twiddles a lane needs in a radix-r stage
+constexpr int imin(int a, int b) { return a < b ? a : b; }
 template <int N> struct TwN {
   using P = Plan<N>;
+  static constexpr int T = N / 8;
+  // register copy: one slot per (butterfly q, input r) of every twiddled stage
   static constexpr int off1 = 0;
   static constexpr int off2 = off1 + tw_count(P::r1);
   static constexpr int off3 = off2 + tw_count(P::r2);
   static constexpr int total = off3 + tw_count(P::r3) + 1;  // +1: never a zero-length array
+  // LDS copy: a stage with NS sub-transform points only has min(NS, T) distinct lane values per
+  // slot (the twiddle index is j mod NS), so a slot is that long instead of T
+  static constexpr int e1 = imin(P::r0, T), e2 = imin(P::r0 * P::r1, T), e3 = imin(P::r0 * P::r1 * P::r2, T);
+  static constexpr int lds1 = 0;
+  static constexpr int lds2 = lds1 + tw_count(P::r1) * e1;
+  static constexpr int lds3 = lds2 + tw_count(P::r2) * e2;
+  static constexpr int lds_total = lds3 + tw_count(P::r3) * e3;  // complex elements
 };
 
 // Twiddles depend on the lane only, so a lane fetches them once (from a float64-rounded table
@@ -158,32 +164,53 @@ __device__ __forceinline__ void load_twiddles(float2 (&tw)[TwN<N>::total], int t
   if constexpr (P::n > 3) load_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::off3>(tw, t, table);
 }
 
-// LDS slot of natural index (t + m*T) relative to lds_pad(t): a compile-time constant, so every
-// exchange addresses LDS as one base VGPR + immediate offsets (no per-slot index registers).
-template <int T>
-__host__ __device__ constexpr int rd_off(int m) { return m * T + ((m * T) >> 3); }
-
 // Where a lane finds its twiddles: its own registers (K_B keeps them across all its rows) or a
-// per-workgroup LDS copy laid out [slot][lane] (K_A, whose raster needs the registers).
+// per-workgroup LDS copy (K_A, whose raster needs the registers).  `at<OFF, LOFF, E>(i)` is slot i
+// of a stage whose register slots start at OFF and whose LDS slots (E entries each) start at LOFF.
 struct TwRegs {
   const float2* p;
-  __device__ __forceinline__ float2 operator[](int i) const { return p[i]; }
+  template <int OFF, int LOFF, int E>
+  __device__ __forceinline__ float2 at(int i) const { return p[OFF + i]; }
 };
-template <int T>
 struct TwLds {
-  const float2* p;  // already offset by the lane index
-  __device__ __forceinline__ float2 operator[](int i) const { return p[i * T]; }
+  const float2* p;
+  int t;  // lane index inside the transform
+  template <int OFF, int LOFF, int E>
+  __device__ __forceinline__ float2 at(int i) const { return p[LOFF + i * E + (t & (E - 1))]; }
 };
 
+// Fill the LDS twiddle table (TwN<N>::lds_total entries) from the global W_N table; called by the
+// T lanes of one transform group.
+template <int N, int R, int NS, int LOFF>
+__device__ __forceinline__ void fill_stage_twiddles(float2* lds, int t, const float2* __restrict__ table) {
+  constexpr int T = N / 8, NB = 8 / R, E = imin(NS, T);
+  if (t < E) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int k = (t + q * T) & (NS - 1);
+#pragma unroll
+      for (int r = 1; r < R; ++r) lds[LOFF + (q * (R - 1) + (r - 1)) * E + t] = table[(r * k * (N / (NS * R))) & (N - 1)];
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void fill_twiddles_lds(float2* lds, int t, const float2* __restrict__ table) {
+  using P = Plan<N>;
+  fill_stage_twiddles<N, P::r1, P::r0, TwN<N>::lds1>(lds, t, table);
+  if constexpr (P::n > 2) fill_stage_twiddles<N, P::r2, P::r0 * P::r1, TwN<N>::lds2>(lds, t, table);
+  if constexpr (P::n > 3) fill_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::lds3>(lds, t, table);
+}
+
+// The exchange buffers are NOT padded: measured on MI355X, neither kernel is sensitive to the
+// LDS bank conflicts of the stride-8 / stride-64 scatters (identical time with and without an extra
+// slot every 8), and the unpadded buffers are what lets four K_A workgroups share a CU.
 // One Stockham stage.  Lane t owns butterflies j = t + q*T (q < 8/R); butterfly j reads
 // in[j + r*N/R] — always the lane's own register slots v[q + r*(8/R)] — and writes
 // out[(j/NS)*NS*R + (j mod NS) + r*NS].  The last stage's outputs land back in the same slots,
 // so on return v[m] = X[t + m*T].
-template <int N, int R, int NS, bool LAST, int OFF, typename TW>
+template <int N, int R, int NS, bool LAST, int OFF, int LOFF, typename TW>
 __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, float2* buf) {
-  constexpr int T = N / 8, NB = 8 / R;
-  static_assert(NS == 1 || NS % 8 == 0, "padding algebra below needs NS = 1 or a multiple of 8");
-  static_assert(NS != 1 || R == 8, "the first stage is radix 8");
+  constexpr int T = N / 8, NB = 8 / R, E = imin(NS, T);
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     float2 a[R];
@@ -191,7 +218,7 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
     for (int r = 0; r < R; ++r) a[r] = v[q + r * NB];
     if constexpr (NS > 1) {
 #pragma unroll
-      for (int r = 1; r < R; ++r) a[r] = cmul(a[r], tw[OFF + q * (R - 1) + (r - 1)]);
+      for (int r = 1; r < R; ++r) a[r] = cmul(a[r], tw.template at<OFF, LOFF, E>(q * (R - 1) + (r - 1)));
     }
     bfly<R>(a);
     if constexpr (LAST) {
@@ -200,19 +227,15 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
     } else {
       const int j = t + q * T;
       const int k = j & (NS - 1);
-      const int j0 = (j - k) * R + k;
-      // lds_pad(j0 + r*NS) = lds_pad(j0) + r * (NS + NS/8)   (NS % 8 == 0), = 9 j + r (NS == 1)
-      float2* const w = buf + lds_pad(j0);
-      constexpr int WS = NS == 1 ? 1 : NS + NS / 8;
+      float2* const w = buf + (j - k) * R + k;  // one base register + immediate offsets r * NS
 #pragma unroll
-      for (int r = 0; r < R; ++r) w[r * WS] = a[r];
+      for (int r = 0; r < R; ++r) w[r * NS] = a[r];
     }
   }
   if constexpr (!LAST) {
     group_sync<T>();
-    const float2* const rd = buf + lds_pad(t);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = rd[rd_off<T>(m)];
+    for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
     group_sync<T>();
   }
 }
@@ -222,16 +245,17 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
 template <int N, typename TW>
 __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   using P = Plan<N>;
-  fft_stage<N, P::r0, 1, false, 0>(v, tw, t, buf);
+  using W = TwN<N>;
+  fft_stage<N, P::r0, 1, false, 0, 0>(v, tw, t, buf);
   if constexpr (P::n == 2) {
-    fft_stage<N, P::r1, P::r0, true, TwN<N>::off1>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, true, W::off1, W::lds1>(v, tw, t, buf);
   } else if constexpr (P::n == 3) {
-    fft_stage<N, P::r1, P::r0, false, TwN<N>::off1>(v, tw, t, buf);
-    fft_stage<N, P::r2, P::r0 * P::r1, true, TwN<N>::off2>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1>(v, tw, t, buf);
+    fft_stage<N, P::r2, P::r0 * P::r1, true, W::off2, W::lds2>(v, tw, t, buf);
   } else {
-    fft_stage<N, P::r1, P::r0, false, TwN<N>::off1>(v, tw, t, buf);
-    fft_stage<N, P::r2, P::r0 * P::r1, false, TwN<N>::off2>(v, tw, t, buf);
-    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, TwN<N>::off3>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1>(v, tw, t, buf);
+    fft_stage<N, P::r2, P::r0 * P::r1, false, W::off2, W::lds2>(v, tw, t, buf);
+    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, W::off3, W::lds3>(v, tw, t, buf);
   }
 }
 
@@ -383,11 +407,11 @@ struct KA {
   static constexpr int NQ = N >= 256 ? (N / HH_KA_BAND > 0 ? N / HH_KA_BAND : 1) : 1;  // workgroups per candidate
   static constexpr int TPW = (N / COLS) / NQ;            // tiles per workgroup
   static constexpr int BAND = TPW * COLS;                // image columns per workgroup
-  static constexpr int BUF = N + N / 8;      // padded complex slots per FFT buffer
-  static constexpr int CL = 1024;            // lattice centres held in LDS at a time
+  static constexpr int BUF = N;              // complex slots per FFT exchange buffer
+  static constexpr int CL = 256;             // lattice centres held in LDS at a time (refilled in chunks beyond)
   static constexpr size_t LDS_FFT = (size_t)FPW * BUF * sizeof(float2);
   static constexpr size_t LDS_CENT = (size_t)CL * sizeof(float2);
-  static constexpr size_t LDS_TW = (size_t)TwN<N>::total * T * sizeof(float2);  // [slot][lane]
+  static constexpr size_t LDS_TW = (size_t)(TwN<N>::lds_total + 1) * sizeof(float2);  // compact twiddle table
   static constexpr size_t LDS = LDS_FFT + LDS_CENT + LDS_TW;
   static_assert(TPW * NQ * COLS == N, "column tiling");
 };
@@ -516,7 +540,7 @@ __device__ __forceinline__ void fill_centres(float2* cent, const Cand& c, const 
 
 template <int N, int MODE, bool RESIDENT>
 __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand& c, int c_lo, int c_hi,
-                                                 const TwLds<N / 8>& tw, float2* bufs, float2* cent) {
+                                                 const TwLds& tw, float2* bufs, float2* cent) {
   using K = KA<N>;
   constexpr int T = K::T;
   const int tid = threadIdx.x;
@@ -564,14 +588,14 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
     // Split Z into the two real columns' spectra: A[k] = (Z[k] + conj Z[N-k]) / 2,
     // B[k] = (Z[k] - conj Z[N-k]) / (2i), k < N/2; ky = 0 and ky = N/2 (both real) share row 0.
 #pragma unroll
-    for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
+    for (int m = 0; m < 8; ++m) buf[t + m * T] = v[m];
     group_sync<T>();
     float4 ab[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int k = t + m * T;
       const float2 zk = v[m];
-      const float2 zm = buf[lds_pad((N - k) & (N - 1))];
+      const float2 zm = buf[(N - k) & (N - 1)];
       ab[m] = make_float4(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y), 0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
     }
     if (t == 0) ab[0] = make_float4(v[0].x, v[4].x, v[0].y, v[4].y);
@@ -636,17 +660,12 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
   }
   const bool resident = (c_hi - c_lo) <= K::CL;  // workgroup-uniform
 
-  // Twiddles: one LDS copy per workgroup, [slot][lane], written by the LAST transform group while
-  // the first lanes are busy with the float64 centre list; one barrier publishes both.
+  // Twiddles: one compact LDS copy per workgroup, written by the LAST transform group while the
+  // first lanes are busy with the float64 centre list; one barrier publishes both.
   float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_FFT + K::LDS_CENT);
-  if (f == K::FPW - 1) {
-    float2 twr[TwN<N>::total];
-    load_twiddles<N>(twr, t, a.twtab);
-#pragma unroll
-    for (int i = 0; i < TwN<N>::total - 1; ++i) twl[i * T + t] = twr[i];
-  }
+  if (f == K::FPW - 1 && !(HH_ABLATE & 8)) fill_twiddles_lds<N>(twl, t, a.twtab);
   __syncthreads();
-  const TwLds<T> tw{twl + t};
+  const TwLds tw{twl, t};
 
   // Two copies of the tile loop: the common one never refills the centre list, so the float64
   // trigonometry of the refill cannot raise its register pressure.
@@ -683,11 +702,11 @@ struct KB {
   static constexpr int BPW = NKB < HH_KB_BPW ? NKB : HH_KB_BPW;  // ky blocks per workgroup
   static constexpr int RPW = 8 * BPW;         // rows per workgroup
   static constexpr int NBLK = NKB / BPW;      // workgroups per candidate
-  static constexpr int BUF = N + N / 8;
+  static constexpr int BUF = N;               // complex slots per FFT exchange buffer
   static constexpr int PROW = N + 2;          // complex slots per panel row (+16 B: conflict-free b128 writes)
   static constexpr size_t LDS_PANEL = (size_t)8 * PROW * sizeof(float2);
   static constexpr size_t LDS_FFT = (size_t)GROUPS * BUF * sizeof(float2);
-  static constexpr size_t LDS = LDS_PANEL + LDS_FFT + (HH_KB_TWLDS ? (size_t)TwN<N>::total * T * sizeof(float2) : 0);
+  static constexpr size_t LDS = LDS_PANEL + LDS_FFT + (HH_KB_TWLDS ? (size_t)(TwN<N>::lds_total + 1) * sizeof(float2) : 0);
   static constexpr int WAVES_PER_SIMD = HH_KB_WPS;  // register budget (512 / WPS VGPRs)
   static_assert(NBLK * BPW == NKB, "row tiling");
 };
@@ -718,14 +737,9 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
 
 #if HH_KB_TWLDS
   float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_PANEL + K::LDS_FFT);
-  if (gi == 0) {
-    float2 twr[TwN<N>::total];
-    load_twiddles<N>(twr, t, a.twtab);
-#pragma unroll
-    for (int i = 0; i < TwN<N>::total - 1; ++i) twl[i * T + t] = twr[i];
-  }
+  if (gi == 0) fill_twiddles_lds<N>(twl, t, a.twtab);
   __syncthreads();
-  const TwLds<T> twsrc{twl + t};
+  const TwLds twsrc{twl, t};
 #else
   float2 tw[TwN<N>::total];
   load_twiddles<N>(tw, t, a.twtab);
@@ -814,14 +828,14 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
     }
     fft_lanes<N>(v, twsrc, t, buf);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) buf[lds_pad(t) + rd_off<T>(m)] = v[m];
+    for (int m = 0; m < 8; ++m) buf[t + m * T] = v[m];
     group_sync<T>();
     if (gi == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int kx = t + m * T;
         const float2 ck = v[m];
-        const float2 cm = buf[lds_pad((N - kx) & (N - 1))];
+        const float2 cm = buf[(N - kx) & (N - 1)];
         const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
         const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
         if constexpr (EPI != EPI_STORE) {
