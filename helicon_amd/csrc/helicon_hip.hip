@@ -711,13 +711,14 @@ struct KB {
   static_assert(NBLK * BPW == NKB, "row tiling");
 };
 
-// q = log1p(|F|) or |F| (transforms.py:807-810).  v_sqrt_f32 / v_log_f32 are 1-ulp hardware
-// ops; log(1 + a) has an ABSOLUTE error of ~1e-7 for every a >= 0, which is what the masked sums
-// see (q enters them linearly and squared, never divided by).
+// q = log1p(|F|) or |F| (transforms.py:807-810), up to a constant factor: the Pearson coefficient is
+// invariant to scaling q, so the logarithm is taken in base 2 (one v_log_f32, no ln 2 multiply).
+// v_sqrt_f32 / v_log_f32 are 1-ulp hardware ops; log2(1 + a) has an ABSOLUTE error of ~1e-7 for
+// every a >= 0, which is what the masked sums see (q enters them linearly and squared).
 template <int LOG>
 __device__ __forceinline__ float amp_to_q(float2 f) {
   const float a = __builtin_amdgcn_sqrtf(f.x * f.x + f.y * f.y);
-  if constexpr (LOG) return __logf(1.0f + a);
+  if constexpr (LOG) return __log2f(1.0f + a);
   return a;
 }
 
