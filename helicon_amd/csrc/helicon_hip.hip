@@ -383,6 +383,7 @@ struct FirstArgs {
   float2* inter;          // [B] x line-blocked half spectrum (inter_index)
   float* raster_out;      // optional [B][N][N]
   FinArgs fin;            // previous batch's scores (one extra workgroup layer, blockIdx.y == B)
+  unsigned long long kb_mask;  // bit kb set: ky block kb is needed downstream (others are not stored)
   DevGeom g;
 };
 
@@ -607,7 +608,8 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
 #pragma unroll
     for (int m = 0; m < ((HH_ABLATE & 4) ? 1 : 4); ++m) {
       const int k = t + m * T;
-      *reinterpret_cast<float4*>(out + inter_index<N>(k, pair)) = ab[m];
+      // ky blocks the mask never looks at are not written (K_B skips them as well)
+      if ((a.kb_mask >> (k >> 3)) & 1ull) *reinterpret_cast<float4*>(out + inter_index<N>(k, pair)) = ab[m];
     }
     group_sync<T>();  // the mirror reads above are done before the next tile's exchange writes
   }
@@ -687,6 +689,8 @@ struct SecondArgs {
   double* partials;       // [B][NBLK][3]                      (EPI_SCORE)
   float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
   float* q_out;           // [B][N/2+1][N] masked q, natural order (EPI_QSTORE)
+  const int* kb_list;     // ky blocks to process (ascending); NULL = all N/16 of them
+  int n_kb;               // entries of kb_list (or N/16)
   int log_flag;
 };
 
@@ -734,7 +738,10 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
   float2* const buf = bufs + gi * K::BUF;
   const size_t b = blockIdx.y;
   const float2* const in = a.inter + b * (size_t)K::ROWS * N;
-  const int kb0 = blockIdx.x * K::BPW;
+  // this workgroup's ky blocks: entries [first, first + nblk) of the (mask-filtered) block list
+  const int first = blockIdx.x * K::BPW;
+  const int nblk = min(K::BPW, a.n_kb - first);
+  auto block_of = [&](int i) { return a.kb_list ? a.kb_list[first + i] : first + i; };
 
 #if HH_KB_TWLDS
   float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_PANEL + K::LDS_FFT);
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
   // (four named registers, not an array: hipcc puts a conditionally re-loaded float4 array in scratch)
   float4 ld0, ld1, ld2, ld3;
   {
-    const float4* src = reinterpret_cast<const float4*>(in + (size_t)kb0 * 8 * N) + tid;
+    const float4* src = reinterpret_cast<const float4*>(in + (size_t)block_of(0) * 8 * N) + tid;
     ld0 = src[0];
     ld1 = src[K::THREADS];
     ld2 = src[2 * K::THREADS];
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
   auto slot = [&](int i) { const int q = i * K::THREADS + tid; return (q & 7) * K::PROW + 2 * (q >> 3); };
 
 #pragma unroll 1
-  for (int blk = 0; blk < K::BPW; ++blk) {
+  for (int blk = 0; blk < nblk; ++blk) {
     // transpose through LDS: panel[r][x]
     *reinterpret_cast<float4*>(panel + slot(0)) = ld0;
     *reinterpret_cast<float4*>(panel + slot(1)) = ld1;
@@ -774,14 +781,14 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = panel[gi * K::PROW + t + m * T];
     __syncthreads();  // the panel may be overwritten; the next block's loads fly under this FFT
-    if (blk + 1 < K::BPW) {
-      const float4* src = reinterpret_cast<const float4*>(in + (size_t)(kb0 + blk + 1) * 8 * N) + tid;
+    if (blk + 1 < nblk) {
+      const float4* src = reinterpret_cast<const float4*>(in + (size_t)block_of(blk + 1) * 8 * N) + tid;
       ld0 = src[0];
       ld1 = src[K::THREADS];
       ld2 = src[2 * K::THREADS];
       ld3 = src[3 * K::THREADS];
     }
-    const int row = (kb0 + blk) * 8 + gi;
+    const int row = block_of(blk) * 8 + gi;
     // this row's weights: 64 contiguous bytes per lane, requested before the FFT so the (L2) latency
     // is covered by the butterflies
     float4 wq0, wq1, wq2, wq3;
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
         r2 += red[3 * w + 1];
         r3 += red[3 * w + 2];
       }
-      double* const o = a.partials + (b * K::NBLK + blockIdx.x) * 3;
+      double* const o = a.partials + (b * gridDim.x + blockIdx.x) * 3;
       o[0] = r1;
       o[1] = r2;
       o[2] = r3;
@@ -1158,6 +1165,9 @@ struct hh_ctx {
   float* d_q = nullptr;          // S > 1: [Bp][K] masked q of one batch, Bp = max_batch rounded up to 64
   float* d_cpart = nullptr;      // S > 1: [N/2+1][Bp][Sp] per-row covariance numerators
   RefConsts* d_ref = nullptr;    // S > 1: [S]
+  int* d_kb_list = nullptr;      // ky blocks (8 rows) the mask touches, ascending; block 0 always
+  int n_kb = 0;
+  unsigned long long kb_mask = ~0ull;
   int s_pad = 0, b_pad = 0;
   float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
   int64_t cap_spec = 0;
@@ -1191,6 +1201,17 @@ int fail(hh_ctx* c, int code, const std::string& msg) {
   } while (0)
 
 bool supported_n(int n) { return n == 32 || n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
+
+int bpw_for(int n) {
+  switch (n) {
+    case 32: return KB<32>::BPW;
+    case 64: return KB<64>::BPW;
+    case 128: return KB<128>::BPW;
+    case 256: return KB<256>::BPW;
+    case 512: return KB<512>::BPW;
+    default: return KB<1024>::BPW;
+  }
+}
 
 int nblk_for(int n) {
   switch (n) {
@@ -1248,7 +1269,8 @@ int launch_second(hh_ctx* c, const SecondArgs& a, int batch) {
     attr_done = true;
   }
   ProfScope ps(c, 1);
-  hipLaunchKernelGGL((k_second_pass<N, EPI, LOG>), dim3(K::NBLK, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  const int grid_x = (a.n_kb + K::BPW - 1) / K::BPW;
+  hipLaunchKernelGGL((k_second_pass<N, EPI, LOG>), dim3(grid_x, batch), dim3(K::THREADS), K::LDS, c->stream, a);
   HH_HIP(c, hipGetLastError());
   return HH_OK;
 }
@@ -1317,6 +1339,7 @@ int spectra_of_images(hh_ctx* c, int count) {
     fa.images = c->d_img + (size_t)s0 * c->n * c->n;
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
+    fa.kb_mask = ~0ull;
     fa.g = c->geom;
     rc = dispatch_first<MODE_IMAGE>(c, fa, nb);
     if (rc) return rc;
@@ -1324,6 +1347,7 @@ int spectra_of_images(hh_ctx* c, int count) {
     sa.inter = c->d_inter;
     sa.twtab = c->d_tw;
     sa.spec_out = c->d_spec + (size_t)s0 * (c->n / 2 + 1) * c->n;
+    sa.n_kb = c->n / 16;
     rc = dispatch_second<EPI_STORE>(c, sa, nb);
     if (rc) return rc;
   }
@@ -1331,7 +1355,7 @@ int spectra_of_images(hh_ctx* c, int count) {
 }
 
 int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
-  const int nblk = nblk_for(c->n);
+  const int nblk = (c->n_kb + bpw_for(c->n) - 1) / bpw_for(c->n);  // K_B workgroups per candidate
   FinArgs pending{};
   int64_t batch_no = 0;
   for (int64_t g0 = 0; g0 < g; g0 += c->max_batch, ++batch_no) {
@@ -1344,6 +1368,7 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
     fa.fin = pending;
+    fa.kb_mask = c->kb_mask;
     fa.g = c->geom;
     int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
     if (rc) return rc;
@@ -1354,6 +1379,8 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     sa.w2 = c->d_w2;
     sa.partials = c->d_partials;
     sa.log_flag = c->log_flag;
+    sa.kb_list = c->d_kb_list;
+    sa.n_kb = c->n_kb;
     if (c->n_segments == 1) {
       rc = dispatch_second<EPI_SCORE>(c, sa, nb);
       if (rc) return rc;
@@ -1547,6 +1574,7 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_q);
   (void)hipFree(c->d_cpart);
   (void)hipFree(c->d_ref);
+  (void)hipFree(c->d_kb_list);
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1663,6 +1691,19 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
       sw += v;
     }
   if (!(sw > 0)) return fail(c, HH_ERR_ARG, "hh_set_reference: the mask selects no Fourier bin");
+  // ky blocks (8 rows of the intermediate) that carry any weight; block 0 also holds the packed
+  // ky = 0 / ky = N/2 row and is always kept.  K_A does not store the others, K_B does not read them.
+  std::vector<int> kb_list;
+  unsigned long long kb_mask = 0;
+  for (int kb = 0; kb < n / 16; ++kb) {
+    bool any = kb == 0;
+    for (int r = 8 * kb; r < 8 * kb + 8 && !any; ++r)
+      for (int kx = 0; kx < n && !any; ++kx) any = w[(size_t)r * n + kx] > 0.f;
+    if (any) {
+      kb_list.push_back(kb);
+      kb_mask |= 1ull << kb;
+    }
+  }
 
   // device tables: W2 (weights, and for one segment the centred spectrum, in K_B's lane-major order);
   // with several segments the centred spectra go to a [Sp][K] matrix for the MFMA contraction
@@ -1715,6 +1756,12 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
                              c->stream));
     HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)b_pad * nh * sizeof(float), c->stream));  // pad rows stay finite
   }
+  if (c->d_kb_list) HH_HIP(c, hipFree(c->d_kb_list));
+  c->d_kb_list = nullptr;
+  HH_HIP(c, hipMalloc(&c->d_kb_list, kb_list.size() * sizeof(int)));
+  HH_HIP(c, hipMemcpyAsync(c->d_kb_list, kb_list.data(), kb_list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->n_kb = (int)kb_list.size();
+  c->kb_mask = kb_mask;
   c->s_pad = s_pad;
   c->b_pad = b_pad;
   HH_HIP(c, hipStreamSynchronize(c->stream));
@@ -1798,6 +1845,7 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
     fa.twtab = c->d_tw;
     fa.inter = c->d_inter;
     fa.raster_out = c->d_img;
+    fa.kb_mask = ~0ull;
     fa.g = c->geom;
     rc = dispatch_first<MODE_RASTER_OUT>(c, fa, 1);
     if (rc == HH_OK) {

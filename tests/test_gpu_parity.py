@@ -454,3 +454,27 @@ def test_seeded_geometry_fuzz_against_oracle():
                                            apix=apix, helical_diameter=d, ball_radius=br, log=bool(case % 2),
                                            rot=p[3], **kw) for p in params])
         np.testing.assert_allclose(got, want, rtol=0, atol=5e-4, err_msg=tag)
+
+
+@pytest.mark.parametrize("kind", ["lowres", "one_block", "high_rows"])
+def test_masks_that_skip_ky_blocks(kind):
+    """Masks that leave whole 8-row ky blocks without weight: the first pass does not store them and the
+    second pass does not read them; scores must be unchanged."""
+    n, apix = 128, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1)
+    ky = np.abs(np.arange(n) - n // 2)[:, None] * np.ones((1, n), int)
+    if kind == "lowres":
+        mask = O.radial_band_mask(n, n, r_lo=3, r_hi=22)
+    elif kind == "one_block":
+        mask = (ky >= 40) & (ky < 48) & O.radial_band_mask(n, n)
+    else:
+        mask = (ky >= 50) & O.radial_band_mask(n, n)
+    twists, rises = np.arange(27.0, 31.5, 1.0), np.array([9.5, 10.0, 10.5])
+    res = H.sweep(img, twists, rises, (1, 2), apix=apix, helical_diameter=d, ball_radius=br, mask=mask)
+    ref = O.sweep_cpu(img, res.grid.params[:, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(res.scores.reshape(-1), ref, rtol=0, atol=SCORE_TOL)
+    # several segments through the same (filtered) block list
+    imgs = np.stack([img, img[::-1].copy()])
+    res2 = H.sweep(imgs, twists, rises, (1,), apix=apix, helical_diameter=d, ball_radius=br, mask=mask)
+    ref2 = O.sweep_cpu(imgs[1], res2.grid.params[:, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(res2.scores[1].reshape(-1), ref2, rtol=0, atol=SCORE_TOL)

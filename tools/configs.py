@@ -11,14 +11,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import helicon_amd as H  # noqa: E402
 
 
-def make(n, n_seg, truth=(1.20, 4.75, 1)):
+def make(n, n_seg, truth=(1.20, 4.75, 1), mask=None):
     eng = H.SweepEngine(n)
     apix = 1.0
     eng.set_geometry(apix=apix, helical_diameter=0.4 * n * apix, ball_radius=2 * apix)
     clean = eng.simulate(*truth)
     imgs = np.stack([(clean + np.random.default_rng(s).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
                      for s in range(n_seg)])
-    eng.set_reference(imgs)
+    eng.set_reference(imgs, mask)
     return eng
 
 
@@ -34,7 +34,7 @@ def run(name, eng, grid, reps=2):
 
 
 tw, rs = H.sweep_axis(0.01, 4.00, 0.01), H.sweep_axis(4.000, 5.245, 0.005)
-which = sys.argv[1:] or ["C3", "C4", "C5"]
+which = sys.argv[1:] or ["C3", "C4", "C5", "LOWRES"]
 if "C3" in which:
     run("C3 512^2, 400x250 grid x Csym 1..6", make(512, 1), H.build_grid(tw, rs, (1, 2, 3, 4, 5, 6), tube_length=512.0), reps=1)
 if "C4" in which:
@@ -43,3 +43,6 @@ if "C4" in which:
 if "C5" in which:
     run("C5 64 segments x 512^2, 200x100 grid", make(512, 64),
         H.build_grid(H.sweep_axis(0.02, 4.00, 0.02), H.sweep_axis(4.25, 5.24, 0.01), (1,), tube_length=512.0))
+if "LOWRES" in which:  # resolution-limited mask: only ky blocks below the cut-off are stored / read
+    run("C2 grid, 512^2, mask 2 < r < 100 (13 of 32 ky blocks)", make(512, 1, mask=H.radial_band_mask(512, 512, 2, 100)),
+        H.build_grid(tw, rs, (1,), tube_length=512.0))
