@@ -36,6 +36,14 @@ def c2_workload(n=512):
                 twists=twists, rises=rises, build_grid=build_grid)
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json (the file travels with the repo); a literal fallback otherwise."""
+    try:
+        return json.loads((ROOT / "BASELINE.json").read_text())["metric"]
+    except Exception:
+        return "helical-param candidates/sec (512\u00b2 image, 100k-pt grid) + HBM roofline %"
+
+
 def usable_cores():
     """Host cores this job may really use: the affinity mask, clipped by the cgroup CPU quota and
     by the 16-core share a one-GPU box grants (override with HELICON_CPU_CORES)."""
@@ -175,7 +183,7 @@ def main():
         value = total / elapsed
         b_alg = eng.algorithmic_bytes()
         out = {
-            "metric": "helical-param candidates/sec (512x512 image, 100k-pt grid)",
+            "metric": baseline_metric(),
             "value": value,
             "unit": "candidates/s",
             "n_gpus": world,
