@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--first-pass", default="auto", choices=["auto", "transform"],
+                    help="auto: run tables on twist-major grids (the default of the library); "
+                         "transform: raster + column transform for every candidate")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,9 +135,12 @@ def main():
     eng.set_stream(stream.cuda_stream)
     d_params = torch.from_numpy(grid.params).to(dev)
     d_scores = torch.empty((1, g_local), dtype=torch.float32, device=dev)
+    h_params = grid.params if args.first_pass == "auto" else None  # the host mirror lets the library see the runs
+    if args.first_pass != "auto":
+        eng.set_table_path(False)
 
     def step():
-        eng.sweep_device(d_params.data_ptr(), g_local, d_scores.data_ptr())
+        eng.sweep_device(d_params.data_ptr(), g_local, d_scores.data_ptr(), host_params=h_params)
         if world > 1:
             local = d_scores if args.backend == "nccl" else d_scores.cpu()
             return gather_scores(local, g_local * world, g_local)
@@ -157,6 +163,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_get() if not args.no_profile else None
+    if prof is not None:
+        prof["candidates_total"] = g_local * args.steps
     eng.profile(0)
 
     # the host-pointer API (params H2D + scores D2H inside the call), reported beside `value`
@@ -199,7 +207,7 @@ def main():
                 "workload": f"C2: {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), "
                             f"400x250 (twist, rise) grid per GPU, Csym = 1, rot = 7.5 deg x rank, radial-band mask, log1p|F|",
                 "image": n, "grid_per_gpu": g_local, "candidates_per_step": g_local * world,
-                "batch": eng.max_batch, "parallelism": f"grid-shard x{world} + all-gather(scores)",
+                "batch": eng.max_batch, "first_pass": eng.last_first_pass, "parallelism": f"grid-shard x{world} + all-gather(scores)",
             },
             "argmax": {"twist": best_pair[0], "rise": best_pair[1], "is_truth": best_pair == (tw0, rs0)},
             "hbm_roofline_frac_wall": value / world * b_alg / HBM_PEAK,
@@ -244,7 +252,10 @@ def roofline(prof, n, b_alg):
         kernels["k_" + name] = {"launches": launches, "avg_us": avg_us, "candidates_per_launch": per_launch,
                                 "alg_bytes_per_candidate": bytes_per_cand, "moves": what, "GBps": gbps,
                                 "frac": gbps / (HBM_PEAK / 1e9), "traffic": measured.get(name)}
-    device_ms = prof["ms_first_pass"] + prof["ms_second_pass"] + prof["ms_finalize"]
+    # run-table builds (one launch per sweep) are timed on every sweep but serve all of its batches:
+    # scale them to the sampled share of the candidates
+    share = cand / max(1, prof.get("candidates_total", cand))
+    device_ms = prof["ms_first_pass"] + prof["ms_second_pass"] + prof["ms_finalize"] + prof["ms_centres"] * share
     achieved = b_alg * cand / (device_ms * 1e-3) / 1e9
     traffic = None
     if all(v["traffic"] is not None for v in kernels.values()):
@@ -254,6 +265,7 @@ def roofline(prof, n, b_alg):
         "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9),
         "traffic": traffic, "alg_bytes_per_candidate": b_alg,
         "candidates_per_launch": cand / prof["n_first_pass"], "device_ms_sampled": device_ms,
+        "run_table_ms_per_sweep": (prof["ms_centres"] / prof["n_centres"]) if prof["n_centres"] else None,
         "kernels": kernels,
     }
 

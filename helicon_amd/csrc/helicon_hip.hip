@@ -32,7 +32,8 @@
 // Tuning knobs (compile-time; defaults are the measured best)
 #ifndef HH_ABLATE
 #define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads,
-                           // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads
+                           // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads; run-table first pass:
+                           // 128 no stores, 256 no accumulation, 1024 no table staging
 #endif
 #ifndef HH_KA_WPS
 #define HH_KA_WPS 8        // K_A: waves per SIMD the register allocator must leave room for (4 workgroups per CU)
@@ -48,6 +49,12 @@
 #endif
 #ifndef HH_KB_BPW
 #define HH_KB_BPW 16       // K_B: ky blocks (of 8 rows) per workgroup
+#endif
+#ifndef HH_KT_PAIRS
+#define HH_KT_PAIRS 32     // run-table first pass: column pairs per workgroup
+#endif
+#ifndef HH_KT_KYW
+#define HH_KT_KYW 128      // run-table first pass: ky rows per workgroup
 #endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
@@ -680,6 +687,217 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
 }
 
 // ------------------------------------------------------------------------------------------
+// K_A, shared-twist form.  The footprint of a subunit is a product ex(x) * ey(y) (square
+// truncation window, Gaussian), so the column transform of the image is
+//     H[ky][x] = sum_c ex_c(x) * G_c[ky],      G_c[ky] = sum_y ey_c(y) W_N^(ky y).
+// Without tilt/psi the row coordinate of subunit (i, s, u) depends on (twist, csym, rot) only and
+// the axial one on (rise, i, u) only.  A sweep visits long runs of candidates that share
+// (twist, csym, rot) — the grid is twist-major (app.py:2319-2403) — so G is tabulated once per run
+// (summed over the csym copies, which share the axial coordinate) and every candidate of the run
+// builds its intermediate from ~(2R+1)/rise_px table rows per column pair: no raster, no column
+// transform.  Output layout and everything downstream are the ones of k_first_pass.
+// ------------------------------------------------------------------------------------------
+struct TableArgs {
+  const double* params;   // [B][4]: the batch's candidates (runs of run_len share twist, csym, rot)
+  const double* units;
+  const float2* twtab;    // [N] exp(-2 pi i k / N)
+  float2* table;          // [runs][cap][N/2]: G rows, slot ky = 0 packs (G[0], G[N/2]) — both real
+  const int* run_imax;    // [runs] subunit index range [-imax, imax] a run's table covers
+  float2* inter;
+  FinArgs fin;
+  unsigned long long kb_mask;
+  int run_len;            // candidates per run inside this batch (>= batch: one run)
+  int cap;                // table rows reserved per run
+  int rows_lds;           // table rows a workgroup of k_first_pass_table can stage
+  DevGeom g;
+};
+
+template <int N>
+struct KT {
+  static constexpr int NKY = N / 2;
+  static constexpr int KYW = NKY < HH_KT_KYW ? NKY : HH_KT_KYW;   // ky rows per workgroup
+  static constexpr int LANES = KYW < 64 ? KYW : 64;   // lanes of a wavefront that own ky rows
+  static constexpr int KPL = KYW / LANES;             // ky rows per lane: ky = ky0 + lane + 64 m
+  static constexpr int THREADS = 256, WAVES = 4;
+  static constexpr int PAIRS_WG = NKY < HH_KT_PAIRS ? NKY : HH_KT_PAIRS;  // column pairs per workgroup
+  static constexpr int COLS = 2 * PAIRS_WG;
+  static constexpr int PPW = PAIRS_WG / WAVES;          // ... and per wavefront, taken two at a time
+  static constexpr int NQX = NKY / PAIRS_WG, NQY = NKY / KYW;
+  static constexpr int ROWS_MAX = 64;                   // table rows a band may need (one lane per row)
+  static constexpr int SUB = 4;                         // table rows per workgroup of k_run_table
+  static_assert(PPW % 2 == 0, "pairs are processed two at a time");
+};
+
+// One table per run: row (i, u) = sum over the csym copies s of G_(i,s,u), for i in [-imax, imax].
+template <int N>
+__global__ __launch_bounds__(256) void k_run_table(TableArgs a) {
+  using K = KT<N>;
+  const int run = blockIdx.y;
+  const DevGeom& g = a.g;
+  Cand c = decode_candidate(a.params + 4 * (size_t)run * a.run_len, g);
+  c.imax = a.run_imax[run];
+  const int rows = (2 * c.imax + 1) * g.n_units;
+  float2* const tab = a.table + (size_t)run * a.cap * K::NKY;
+  const float rp = (float)g.rpx;
+  const float k2 = g.inv_sigma2 * 1.44269504088896341f;
+  for (int row = blockIdx.x * K::SUB; row < min(rows, (int)(blockIdx.x + 1) * K::SUB); ++row) {
+    const int ir = row / g.n_units, u = row % g.n_units;
+    for (int ky = threadIdx.x; ky < K::NKY; ky += 256) {
+      float2 acc = make_float2(0.f, 0.f);
+      float alt = 0.f;  // ky = N/2: sum ey (-1)^y
+      for (int s = 0; s < c.csym; ++s) {
+        const float yc = centre_position(c, g, a.units, (ir * c.csym + s) * g.n_units + u).x;
+        const float cy = yc * g.inv_apix + (float)(N / 2);
+        if (!(cy >= -rp - 1.f && cy <= (float)N + rp)) continue;
+        const int y0 = max(0, (int)ceilf(cy - rp)), y1 = min(N - 1, (int)floorf(cy + rp));
+        for (int y = y0; y <= y1; ++y) {
+          const float dyv = (float)(y - N / 2) * g.apix - yc;
+          const float e = __builtin_amdgcn_exp2f(-dyv * dyv * k2);
+          const float2 w = a.twtab[(ky * y) & (N - 1)];
+          acc.x = fmaf(e, w.x, acc.x);
+          acc.y = fmaf(e, w.y, acc.y);
+          alt += (y & 1) ? -e : e;
+        }
+      }
+      if (ky == 0) acc.y = alt;
+      tab[(size_t)row * K::NKY + ky] = acc;
+    }
+  }
+}
+
+// A workgroup owns COLS image columns x KYW ky rows of one candidate and stages in LDS the table
+// rows whose subunits can reach its band (at most rows_lds, which the host sized from the smallest
+// rise of the sweep).  A wavefront then takes its column pairs two at a time: lane j evaluates the
+// four column factors ex(x) of table row j (all rows in parallel), and the rows that reach the four
+// columns are accumulated with the factors broadcast by v_readlane (scalar operands) — per row two
+// LDS reads of G feed sixteen FMAs.  Each group of two pairs is stored as soon as it is complete.
+template <int N>
+__global__ __launch_bounds__(256) void k_first_pass_table(TableArgs a) {
+  using K = KT<N>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* const lds_g = reinterpret_cast<float2*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {  // the extra layer: scores of the previous batch
+    if (blockIdx.x == 0)
+      for (int i = tid; i < a.fin.n; i += K::THREADS)
+        a.fin.scores[i] = finalize_one(a.fin.partials, a.fin.nblk, i, a.fin.rc);
+    return;
+  }
+  const int band = blockIdx.x % K::NQX, slice = blockIdx.x / K::NQX;
+  const int x0 = band * K::COLS, ky0 = slice * K::KYW;
+  {
+    // ky blocks the mask never looks at are not produced (K_B skips them as well)
+    const unsigned long long bits = K::KYW >= 512 ? ~0ull : ((1ull << (K::KYW / 8)) - 1ull) << (ky0 / 8);
+    if (!(a.kb_mask & bits)) return;
+  }
+  const size_t b = blockIdx.y;
+  const DevGeom& g = a.g;
+  const Cand c = decode_candidate(a.params + 4 * b, g);
+  const int run = (int)(b / (size_t)a.run_len);
+  const int imax_t = a.run_imax[run];
+  const float2* const tab = a.table + (size_t)run * a.cap * K::NKY;
+  float2* const out = a.inter + b * (size_t)(N / 2) * N;
+  const float rp = (float)g.rpx;
+  const float k2 = g.inv_sigma2 * 1.44269504088896341f;
+  const bool owner = lane < K::LANES;
+
+  // subunit indices whose footprint can reach the band (axial coordinate = z_u + i * rise; the
+  // slack covers |z_u| and the float32 roundings of the products)
+  int ilo = 0, rows = 0;
+  if (c.M > 0) {
+    const float inv_rise = 1.0f / (float)c.rise;
+    const float i0 = ((float)(x0 - N / 2) * g.apix - rp * g.apix - g.slack) * inv_rise;
+    const float i1 = ((float)(x0 + K::COLS - 1 - N / 2) * g.apix + rp * g.apix + g.slack) * inv_rise;
+    ilo = max(-c.imax, (int)floorf(fmaxf(i0, -2.0e9f)));
+    const int ihi = min(c.imax, (int)ceilf(fminf(i1, 2.0e9f)));
+    rows = ihi < ilo ? 0 : min(a.rows_lds, (ihi - ilo + 1) * g.n_units);
+  }
+  if (!(HH_ABLATE & 1024)) {
+    // stage the rows: all of a thread's loads are issued before the first LDS write waits for one
+    const float2* const src = tab + ((size_t)(ilo + imax_t) * g.n_units) * K::NKY + ky0;
+    constexpr int PER = K::KYW / 2;                 // float4 per staged row
+    constexpr int STEP = K::THREADS / PER;          // rows covered by one pass of the workgroup
+    const int q = tid % PER, j0 = tid / PER;
+#pragma unroll 1
+    for (int jb = 0; jb < rows; jb += 8 * STEP) {
+      float4 v[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int j = min(jb + j0 + s * STEP, rows - 1);  // unconditional: the loads stay in flight together
+        v[s] = *reinterpret_cast<const float4*>(src + (size_t)j * K::NKY + 2 * q);
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int j = min(jb + j0 + s * STEP, rows - 1);  // past the end: the last row again, same data
+        *reinterpret_cast<float4*>(lds_g + j * K::KYW + 2 * q) = v[s];
+      }
+    }
+  }
+  // lane j: axial position of table row j
+  float xc = 0.f, cx = -1.0e9f;
+  if (lane < rows) {
+    int i = ilo + lane, u = 0;
+    if (g.n_units > 1) {
+      i = ilo + lane / g.n_units;
+      u = lane % g.n_units;
+    }
+    xc = (float)a.units[3 * u + 2] + (float)((double)i * c.rise);  // utils.py:160, float32 like the lattice list
+    cx = xc * g.inv_apix + (float)(N / 2);
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int pg = 0; pg < K::PPW / 2; ++pg) {
+    const int pair = (x0 >> 1) + wave * K::PPW + 2 * pg;
+    const int xa = 2 * pair;
+    float w[4];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float dx = (float)(xa + q - N / 2) * g.apix - xc;
+      const bool in = fabsf((float)(xa + q) - cx) <= rp;
+      w[q] = in ? __builtin_amdgcn_exp2f(-dx * dx * k2) : 0.f;
+      any |= in;
+    }
+    unsigned long long todo = (HH_ABLATE & 256) ? 0ull : __ballot(any);
+    float2 acc[4][K::KPL];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < K::KPL; ++m) acc[q][m] = make_float2(0.f, 0.f);
+    while (todo) {  // ascending rows: every sum has a fixed order
+      const int j = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      float e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[q]), j));
+      if (owner) {
+#pragma unroll
+        for (int m = 0; m < K::KPL; ++m) {
+          const float2 gk = lds_g[j * K::KYW + lane + 64 * m];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[q][m].x = fmaf(e[q], gk.x, acc[q][m].x);
+            acc[q][m].y = fmaf(e[q], gk.y, acc[q][m].y);
+          }
+        }
+      }
+    }
+    if (owner) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = 0; m < K::KPL; ++m) {
+          const int k = ky0 + lane + 64 * m;
+          if (((a.kb_mask >> (k >> 3)) & 1ull) && (!(HH_ABLATE & 128) || acc[0][m].x == 12345.678f))
+            *reinterpret_cast<float4*>(out + inter_index<N>(k, pair + h)) =
+                make_float4(acc[2 * h][m].x, acc[2 * h][m].y, acc[2 * h + 1][m].x, acc[2 * h + 1][m].y);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K_B: row FFT + amplitude + masked moments (or: store the half-plane spectrum)
 // ------------------------------------------------------------------------------------------
 struct SecondArgs {
@@ -1167,6 +1385,13 @@ struct hh_ctx {
   RefConsts* d_ref = nullptr;    // S > 1: [S]
   int* d_kb_list = nullptr;      // ky blocks (8 rows) the mask touches, ascending; block 0 always
   int n_kb = 0;
+  float2* d_table = nullptr;     // shared-twist first pass: [runs per batch][rows][N/2] column-transform table
+  size_t cap_table = 0;          // bytes
+  int* d_run_imax = nullptr;     // [runs of the sweep]
+  int64_t cap_runs = 0;
+  std::vector<int> h_run_imax;
+  int table_path = 1;            // 0: never take the shared-twist first pass
+  int last_first_pass = 0;       // what the last sweep ran: 0 per-candidate transform, 1 run tables
   unsigned long long kb_mask = ~0ull;
   int s_pad = 0, b_pad = 0;
   float2* d_spec = nullptr;      // [N/2+1][N] scratch (grown for S segments)
@@ -1354,7 +1579,234 @@ int spectra_of_images(hh_ctx* c, int count) {
   return HH_OK;
 }
 
-int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
+template <int N>
+int launch_run_table(hh_ctx* c, const TableArgs& a, int runs, int rows) {
+  using K = KT<N>;
+  ProfScope ps(c, 3);
+  hipLaunchKernelGGL((k_run_table<N>), dim3((rows + K::SUB - 1) / K::SUB, runs), dim3(256), 0, c->stream, a);
+  HH_HIP(c, hipGetLastError());
+  return HH_OK;
+}
+
+template <int N>
+int launch_first_table(hh_ctx* c, const TableArgs& a, int batch) {
+  using K = KT<N>;
+  ProfScope ps(c, 0);
+  const size_t lds = (size_t)a.rows_lds * K::KYW * sizeof(float2);
+  hipLaunchKernelGGL((k_first_pass_table<N>), dim3(K::NQX * K::NQY, batch + (a.fin.n > 0 ? 1 : 0)), dim3(K::THREADS),
+                     lds, c->stream, a);
+  HH_HIP(c, hipGetLastError());
+  return HH_OK;
+}
+
+#define HH_SWITCH_N(c, CALL)                                        \
+  switch ((c)->n) {                                                 \
+    case 32: return CALL(32);                                       \
+    case 64: return CALL(64);                                       \
+    case 128: return CALL(128);                                     \
+    case 256: return CALL(256);                                     \
+    case 512: return CALL(512);                                     \
+    case 1024: return CALL(1024);                                   \
+  }                                                                 \
+  return fail(c, HH_ERR_ARG, "unsupported image size")
+
+int dispatch_run_table(hh_ctx* c, const TableArgs& a, int runs, int rows) {
+#define HH_CALL(NN) launch_run_table<NN>(c, a, runs, rows)
+  HH_SWITCH_N(c, HH_CALL);
+#undef HH_CALL
+}
+
+int dispatch_first_table(hh_ctx* c, const TableArgs& a, int batch) {
+#define HH_CALL(NN) launch_first_table<NN>(c, a, batch)
+  HH_SWITCH_N(c, HH_CALL);
+#undef HH_CALL
+}
+
+// A candidate list the shared-twist first pass can take: runs of `len` consecutive candidates with
+// identical (twist, csym, rot) and positive finite rises; h_run_imax[r] = the subunit index range
+// of run r (from its smallest rise).
+struct RunPlan {
+  bool ok = false;
+  int64_t len = 0;
+  int rows = 0;      // table rows per run: (2 max imax + 1) * n_units
+  int rows_lds = 0;  // table rows a band of image columns can need (from the smallest rise)
+};
+
+constexpr int64_t HH_MIN_RUN = 32;             // shorter runs do not amortise their table
+constexpr size_t HH_TABLE_BYTES_MAX = 1ull << 30;
+
+int table_cols(int n) {
+  switch (n) {
+    case 32: return KT<32>::COLS;
+    case 64: return KT<64>::COLS;
+    case 128: return KT<128>::COLS;
+    case 256: return KT<256>::COLS;
+    case 512: return KT<512>::COLS;
+    default: return KT<1024>::COLS;
+  }
+}
+
+RunPlan plan_runs(hh_ctx* c, const double* hp, int64_t g) {
+  RunPlan plan;
+  if (!hp || !c->table_path || c->geom.has_rot || g < HH_MIN_RUN) return plan;
+  int64_t len = 1;
+  while (len < g && hp[4 * len] == hp[0] && hp[4 * len + 2] == hp[2] && hp[4 * len + 3] == hp[3]) ++len;
+  if (len < HH_MIN_RUN || g % len) return plan;
+  const int64_t runs = g / len;
+  c->h_run_imax.assign((size_t)runs, 0);
+  int imax_all = 0;
+  double rise_all = INFINITY;
+  for (int64_t r = 0; r < runs; ++r) {
+    const double* p = hp + 4 * r * len;
+    double rise_min = INFINITY;
+    for (int64_t k = 0; k < len; ++k) {
+      const double* q = p + 4 * k;
+      if (!(q[0] == p[0] && q[2] == p[2] && q[3] == p[3])) return plan;
+      if (!(q[1] > 0.0) || !(q[1] < INFINITY)) return plan;
+      rise_min = std::min(rise_min, q[1]);
+    }
+    const double im = std::ceil(c->geom.height / rise_min);
+    if (im > 1048576.0) return plan;
+    c->h_run_imax[(size_t)r] = (int)im;
+    imax_all = std::max(imax_all, (int)im);
+    rise_all = std::min(rise_all, rise_min);
+  }
+  // k_first_pass_table: rows = ceil(i1) - floor(i0) + 1 <= (i1 - i0) + 3 with
+  // i1 - i0 = ((COLS - 1) apix + 2 rpx apix + 2 slack) / rise; one more row for float32 rounding
+  const double span = ((double)(table_cols(c->n) - 1) + 2.0 * c->geom.rpx) * c->geom.apix + 2.0 * c->geom.slack;
+  const double need = (std::floor(span / (double)(float)rise_all) + 4.0) * c->geom.n_units;
+  if (need > 64.0) return plan;  // KT<N>::ROWS_MAX: one lane per staged row
+  plan.rows_lds = (int)need;
+  plan.rows = (2 * imax_all + 1) * c->geom.n_units;
+  if ((size_t)plan.rows * (c->n / 2) * sizeof(float2) > HH_TABLE_BYTES_MAX) return plan;
+  plan.len = len;
+  plan.ok = true;
+  return plan;
+}
+
+// Second pass + scores of one batch whose intermediate is in c->d_inter.
+int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, int nblk, float* d_scores, FinArgs& pending) {
+  SecondArgs sa{};
+  sa.inter = c->d_inter;
+  sa.twtab = c->d_tw;
+  sa.w2 = c->d_w2;
+  sa.partials = c->d_partials;
+  sa.log_flag = c->log_flag;
+  sa.kb_list = c->d_kb_list;
+  sa.n_kb = c->n_kb;
+  int rc;
+  if (c->n_segments == 1) {
+    rc = dispatch_second<EPI_SCORE>(c, sa, nb);
+    if (rc) return rc;
+    float* const out = d_scores + g0;
+    if (g0 + nb < g) {
+      pending = FinArgs{c->d_partials, out, nb, nblk, c->ref[0]};
+    } else {
+      ProfScope ps(c, 2);
+      hipLaunchKernelGGL(k_finalize, dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
+                         (int64_t)nb, c->ref[0], out);
+    }
+    HH_HIP(c, hipGetLastError());
+  } else {
+    // several segments: q of the batch -> HBM, one MFMA contraction against all segments' centred
+    // spectra, then Pearson per (segment, candidate)
+    sa.q_out = c->d_q;
+    rc = dispatch_second<EPI_QSTORE>(c, sa, nb);
+    if (rc) return rc;
+    const int rows = c->n / 2 + 1;
+    const size_t K = (size_t)rows * c->n;
+    ProfScope ps(c, 2);
+    hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
+                       c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
+    const int total = nb * c->n_segments;
+    hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
+                       c->d_cpart, rows, c->b_pad, c->s_pad, nb, c->n_segments, c->d_ref, d_scores, g, g0);
+    HH_HIP(c, hipGetLastError());
+  }
+  return HH_OK;
+}
+
+// The sweep with the shared-twist first pass (plan.ok): batches are whole runs (or pieces of one
+// run); the tables of as many runs as fit HH_TABLE_BYTES_MAX are built by one launch ahead of them.
+int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const RunPlan& plan) {
+  const int nblk = (c->n_kb + bpw_for(c->n) - 1) / bpw_for(c->n);
+  const int64_t runs = g / plan.len;
+  const int nky = c->n / 2;
+  const int64_t per_batch = plan.len <= c->max_batch ? c->max_batch / plan.len : 1;
+  const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
+  int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
+  per_group = std::min<int64_t>(std::min<int64_t>(per_group, runs), 65535);
+  if (per_group > per_batch) per_group -= per_group % per_batch;
+  const size_t need = (size_t)per_group * run_bytes;
+  if (need > c->cap_table) {
+    if (c->d_table) HH_HIP(c, hipFree(c->d_table));
+    c->d_table = nullptr;
+    c->cap_table = 0;
+    HH_HIP(c, hipMalloc(&c->d_table, need));
+    c->cap_table = need;
+  }
+  if (runs > c->cap_runs) {
+    if (c->d_run_imax) HH_HIP(c, hipFree(c->d_run_imax));
+    c->d_run_imax = nullptr;
+    c->cap_runs = 0;
+    HH_HIP(c, hipMalloc(&c->d_run_imax, (size_t)runs * sizeof(int)));
+    c->cap_runs = runs;
+  }
+  HH_HIP(c, hipMemcpyAsync(c->d_run_imax, c->h_run_imax.data(), (size_t)runs * sizeof(int), hipMemcpyHostToDevice,
+                           c->stream));
+  TableArgs ta{};
+  ta.units = c->d_units;
+  ta.twtab = c->d_tw;
+  ta.inter = c->d_inter;
+  ta.kb_mask = c->kb_mask;
+  ta.cap = plan.rows;
+  ta.rows_lds = plan.rows_lds;
+  ta.g = c->geom;
+  FinArgs pending{};
+  int64_t batch_no = 0;
+  for (int64_t q0 = 0; q0 < runs; q0 += per_group) {
+    const int nq = (int)std::min<int64_t>(per_group, runs - q0);
+    {
+      c->prof_now = c->profiling > 0;
+      ta.params = d_params + 4 * q0 * plan.len;
+      ta.table = c->d_table;
+      ta.run_imax = c->d_run_imax + q0;
+      ta.run_len = (int)std::min<int64_t>(plan.len, 1 << 30);
+      ta.fin = FinArgs{};
+      int rows = 0;
+      for (int r = 0; r < nq; ++r) rows = std::max(rows, (2 * c->h_run_imax[(size_t)(q0 + r)] + 1) * c->geom.n_units);
+      const int rc = dispatch_run_table(c, ta, nq, rows);
+      if (rc) return rc;
+    }
+    for (int64_t r0 = q0; r0 < q0 + nq; r0 += per_batch) {
+      const int nr = (int)std::min<int64_t>(per_batch, q0 + nq - r0);
+      ta.table = c->d_table + (size_t)(r0 - q0) * plan.rows * nky;
+      ta.run_imax = c->d_run_imax + r0;
+      ta.run_len = plan.len <= c->max_batch ? (int)plan.len : c->max_batch + 1;
+      // pieces of the run(s): one piece when a batch holds whole runs
+      const int64_t first = r0 * plan.len, count = (int64_t)nr * plan.len;
+      for (int64_t g0 = first; g0 < first + count; g0 += c->max_batch, ++batch_no) {
+        const int nb = (int)std::min<int64_t>(c->max_batch, first + count - g0);
+        c->prof_now = c->profiling > 0 && (batch_no % c->profiling) == 0;
+        if (c->prof_now) c->prof_candidates += nb;
+        ta.params = d_params + 4 * g0;
+        ta.fin = pending;
+        int rc = dispatch_first_table(c, ta, nb);
+        if (rc) return rc;
+        pending = FinArgs{};
+        rc = second_and_scores(c, g, g0, nb, nblk, d_scores, pending);
+        if (rc) return rc;
+      }
+    }
+  }
+  c->prof_now = false;
+  return HH_OK;
+}
+
+int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const double* h_params = nullptr) {
+  const RunPlan plan = plan_runs(c, h_params, g);
+  c->last_first_pass = plan.ok ? 1 : 0;
+  if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan);
   const int nblk = (c->n_kb + bpw_for(c->n) - 1) / bpw_for(c->n);  // K_B workgroups per candidate
   FinArgs pending{};
   int64_t batch_no = 0;
@@ -1373,42 +1825,8 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
     if (rc) return rc;
     pending = FinArgs{};
-    SecondArgs sa{};
-    sa.inter = c->d_inter;
-    sa.twtab = c->d_tw;
-    sa.w2 = c->d_w2;
-    sa.partials = c->d_partials;
-    sa.log_flag = c->log_flag;
-    sa.kb_list = c->d_kb_list;
-    sa.n_kb = c->n_kb;
-    if (c->n_segments == 1) {
-      rc = dispatch_second<EPI_SCORE>(c, sa, nb);
-      if (rc) return rc;
-      float* const out = d_scores + g0;
-      if (g0 + nb < g) {
-        pending = FinArgs{c->d_partials, out, nb, nblk, c->ref[0]};
-      } else {
-        ProfScope ps(c, 2);
-        hipLaunchKernelGGL(k_finalize, dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
-                           (int64_t)nb, c->ref[0], out);
-      }
-      HH_HIP(c, hipGetLastError());
-    } else {
-      // several segments: q of the batch -> HBM, one MFMA contraction against all segments' centred
-      // spectra, then Pearson per (segment, candidate)
-      sa.q_out = c->d_q;
-      rc = dispatch_second<EPI_QSTORE>(c, sa, nb);
-      if (rc) return rc;
-      const int rows = c->n / 2 + 1;
-      const size_t K = (size_t)rows * c->n;
-      ProfScope ps(c, 2);
-      hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
-                         c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
-      const int total = nb * c->n_segments;
-      hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
-                         c->d_cpart, rows, c->b_pad, c->s_pad, nb, c->n_segments, c->d_ref, d_scores, g, g0);
-      HH_HIP(c, hipGetLastError());
-    }
+    rc = second_and_scores(c, g, g0, nb, nblk, d_scores, pending);
+    if (rc) return rc;
   }
   c->prof_now = false;
   return HH_OK;
@@ -1575,6 +1993,9 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_cpart);
   (void)hipFree(c->d_ref);
   (void)hipFree(c->d_kb_list);
+  (void)hipFree(c->d_table);
+  (void)hipFree(c->d_run_imax);
+
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1779,6 +2200,23 @@ int hh_sweep_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
   return sweep_on_device(c, d_params, g, d_scores);
 }
 
+int hh_sweep_device_mirrored(hh_ctx* c, const double* d_params, const double* h_params, int64_t g, float* d_scores) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (!d_params || !d_scores || g < 0) return fail(c, HH_ERR_ARG, "hh_sweep_device_mirrored: bad argument");
+  if (g == 0) return HH_OK;
+  HH_HIP(c, hipSetDevice(c->device));
+  return sweep_on_device(c, d_params, g, d_scores, h_params);
+}
+
+int hh_last_first_pass(const hh_ctx* c) { return c ? c->last_first_pass : HH_ERR_ARG; }
+
+int hh_set_table_path(hh_ctx* c, int on) {
+  if (!c) return HH_ERR_ARG;
+  c->table_path = on ? 1 : 0;
+  return HH_OK;
+}
+
 int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
   int rc = check_ready(c, true);
   if (rc) return rc;
@@ -1804,7 +2242,7 @@ int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
   }
   hipError_t e = hipMemcpyAsync(c->d_params, params, (size_t)g * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
-    rc = sweep_on_device(c, c->d_params, g, d_sc);
+    rc = sweep_on_device(c, c->d_params, g, d_sc, params);
     if (rc == HH_OK) {
       e = hipMemcpyAsync(scores, d_sc, (size_t)g * c->n_segments * sizeof(float), hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -155,12 +155,31 @@ class SweepEngine:
             self._check(self._L.hh_sweep(self._ctx, _ptr(p, C.c_double), len(p), _ptr(out, C.c_float)))
         return out
 
-    def sweep_device(self, d_params: int, n_candidates: int, d_scores: int):
+    def sweep_device(self, d_params: int, n_candidates: int, d_scores: int, host_params=None):
         """Device pointers (ints): params [G, 4] float64, scores [S, G] float32; asynchronous on
-        the engine's stream."""
+        the engine's stream.  ``host_params`` = the same [G, 4] list on the host, if the caller has
+        it: it lets the library take the shared-twist first pass on twist-major grids
+        (``hh_sweep_device_mirrored``)."""
         with self._lock:
-            self._check(self._L.hh_sweep_device(self._ctx, C.c_void_p(d_params), int(n_candidates),
-                                                C.c_void_p(d_scores)))
+            if host_params is None:
+                self._check(self._L.hh_sweep_device(self._ctx, C.c_void_p(d_params), int(n_candidates),
+                                                    C.c_void_p(d_scores)))
+            else:
+                hp = np.ascontiguousarray(host_params, dtype=np.float64)
+                if hp.shape != (int(n_candidates), 4):
+                    raise ValueError("host_params must be [n_candidates, 4]")
+                self._check(self._L.hh_sweep_device_mirrored(self._ctx, C.c_void_p(d_params), _ptr(hp, C.c_double),
+                                                             int(n_candidates), C.c_void_p(d_scores)))
+
+    def set_table_path(self, on: bool):
+        """Allow (default) or forbid the shared-twist first pass; scores agree to float32 rounding."""
+        with self._lock:
+            self._check(self._L.hh_set_table_path(self._ctx, int(bool(on))))
+
+    @property
+    def last_first_pass(self) -> str:
+        """First pass of the last sweep: "transform" (per candidate) or "run_tables" (shared twist)."""
+        return "run_tables" if self._L.hh_last_first_pass(self._ctx) == 1 else "transform"
 
     def synchronize(self):
         with self._lock:

@@ -478,3 +478,126 @@ def test_masks_that_skip_ky_blocks(kind):
     res2 = H.sweep(imgs, twists, rises, (1,), apix=apix, helical_diameter=d, ball_radius=br, mask=mask)
     ref2 = O.sweep_cpu(imgs[1], res2.grid.params[:, :3], mask, apix=apix, helical_diameter=d, ball_radius=br)
     np.testing.assert_allclose(res2.scores[1].reshape(-1), ref2, rtol=0, atol=SCORE_TOL)
+
+
+# ---------------------------------------------------------------------------- shared-twist first pass
+def _both_first_passes(eng, params):
+    """Scores of the same list through the run-table first pass and through the per-candidate transform."""
+    eng.set_table_path(True)
+    tab = eng.sweep(params)
+    used = eng.last_first_pass
+    eng.set_table_path(False)
+    gen = eng.sweep(params)
+    assert eng.last_first_pass == "transform"
+    eng.set_table_path(True)
+    return tab, gen, used
+
+
+@pytest.mark.parametrize("n,apix,max_batch,csyms,kw", [
+    (128, 2.0, 0, (1, 3), dict(rot=33.0, dy=3.0)),   # whole runs per batch
+    (128, 2.0, 100, (1,), dict()),                    # two runs per batch, last batch one run
+    (128, 2.0, 16, (2,), dict(dy=-4.0)),              # a run longer than the batch: pieces share one table
+    (64, 2.0, 0, (1, 2, 5), dict(rot=-120.0)),
+    (32, 3.3, 0, (1,), dict()),
+    (256, 1.0, 0, (1,), dict()),
+])
+def test_run_table_first_pass_matches_transform_and_oracle(n, apix, max_batch, csyms, kw):
+    """A twist-major grid with 40 rises per twist takes the run-table first pass (hh_sweep sees the
+    host list); scores must equal the per-candidate transform's and the oracle's."""
+    tw0, rs0 = (29.0, 10.0) if n < 256 else (1.2, 4.75)
+    img, d, br = _noisy_helix(n, apix, tw0, rs0, 1, seed=7)
+    twists = tw0 + np.array([-1.0, -0.3, 0.0, 0.4, 1.1])
+    rises = rs0 + np.linspace(-0.4, 0.4, 40)
+    rot = kw.get("rot", 0.0)
+    geo = {k: v for k, v in kw.items() if k != "rot"}
+    from helicon_amd.grid import build_grid
+    grid = build_grid(twists, rises, csyms, tube_length=n * apix, rot=rot)
+    assert grid.valid.all()
+    mask = O.radial_band_mask(n, n)
+    with H.SweepEngine(n, max_batch=max_batch) as eng:
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, **geo)
+        eng.set_reference(img, mask)
+        tab, gen, used = _both_first_passes(eng, grid.params)
+    assert used == "run_tables"
+    np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
+    pick = np.arange(0, len(grid), 7 if n < 256 else 23)
+    ref = O.sweep_cpu(img, grid.params[pick, :3], mask, apix=apix, helical_diameter=d, ball_radius=br, rot=rot, **geo)
+    np.testing.assert_allclose(tab[0, pick], ref, rtol=0, atol=SCORE_TOL)
+    assert int(np.argmax(tab[0])) == int(np.argmax(gen[0]))
+
+
+def test_run_table_first_pass_units_segments_masks_and_fallbacks():
+    n, apix = 64, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1, seed=3)
+    from helicon_amd.grid import build_grid
+    grid = build_grid(np.array([27.5, 29.0, 30.25]), 10.0 + np.linspace(-1.5, 1.5, 36), (1, 2), tube_length=n * apix)
+    units3 = np.array([[0.5 * d, 0.0, 0.0], [0.35 * d, 1.1, 3.7], [0.2 * d, -2.0, -5.2]])  # radius, azimuth rad, axial A
+    units = units3[:2]
+    ky = np.abs(np.arange(n) - n // 2)[:, None] * np.ones((1, n), int)
+    masks = [O.radial_band_mask(n, n), (ky >= 8) & (ky < 24) & O.radial_band_mask(n, n)]
+    with H.SweepEngine(n) as eng:
+        for k, mask in enumerate(masks):
+            # several subunits per asymmetric unit (axial offsets enter the column factor, the rest the table)
+            eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, units=units, dy=1.5 * k)
+            eng.set_reference(img, mask, log=bool(k))
+            tab, gen, used = _both_first_passes(eng, grid.params)
+            assert used == "run_tables"
+            np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
+        # several segments: the contraction path behind the same first pass
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        eng.set_reference(np.stack([img, img[::-1].copy(), img[:, ::-1].copy()]), masks[0])
+        tab, gen, used = _both_first_passes(eng, grid.params)
+        assert used == "run_tables" and tab.shape == (3, len(grid))
+        np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
+        ref = O.sweep_cpu(img[::-1].copy(), grid.params[::9, :3], masks[0], apix=apix, helical_diameter=d, ball_radius=br)
+        np.testing.assert_allclose(tab[1, ::9], ref, rtol=0, atol=SCORE_TOL)
+
+        # lists the plan must refuse: ragged runs, a run that is too short, a bad rise, tilt/psi
+        eng.set_reference(img, masks[0])
+        for bad in (grid.params[:-5], grid.params[:20], np.vstack([grid.params[:36], grid.params[40:76]])):
+            eng.sweep(bad)
+            assert eng.last_first_pass == "transform"
+        holes = grid.params.copy()
+        holes[50, 1] = -1.0  # a skipped pair as the driver marks it
+        got = eng.sweep(holes)
+        assert eng.last_first_pass == "transform"
+        keep = np.arange(len(holes)) != 50
+        np.testing.assert_allclose(got[0, keep], gen[0, keep], rtol=0, atol=2e-5)
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, tilt=3.0)
+        eng.sweep(grid.params)
+        assert eng.last_first_pass == "transform"
+        # more table rows per band of columns than a workgroup stages (64): three subunits here, tiny rises below
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, units=units3)
+        eng.sweep(grid.params)
+        assert eng.last_first_pass == "transform"
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        dense = grid.params.copy()
+        dense[:, 1] *= 0.2
+        eng.sweep(dense)
+        assert eng.last_first_pass == "transform"
+
+
+def test_run_table_first_pass_device_api_full_sizes():
+    """hh_sweep_device_mirrored at 512 and 1024 on runs of 64 rises, against hh_sweep_device."""
+    import torch
+    for n, tw0, rs0, cs in ((512, 1.20, 4.75, 1), (1024, 2.4, 9.5, 2)):
+        apix = 1.0
+        d, br = 0.4 * n * apix, 2 * apix
+        from helicon_amd.grid import build_grid
+        grid = build_grid(tw0 + np.array([-0.5, 0.0, 0.37]), rs0 + 0.005 * np.arange(-32, 32), (cs,), tube_length=n * apix)
+        with H.SweepEngine(n) as eng:
+            eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+            clean = eng.simulate(tw0, rs0, cs)
+            img = (clean + np.random.default_rng(5).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
+            eng.set_reference(img)
+            dp = torch.from_numpy(grid.params).cuda()
+            a = torch.empty((1, len(grid)), dtype=torch.float32, device="cuda")
+            b = torch.empty_like(a)
+            eng.sweep_device(dp.data_ptr(), len(grid), a.data_ptr(), host_params=grid.params)
+            assert eng.last_first_pass == "run_tables"
+            eng.sweep_device(dp.data_ptr(), len(grid), b.data_ptr())
+            assert eng.last_first_pass == "transform"
+            eng.synchronize()
+            a, b = a.cpu().numpy()[0], b.cpu().numpy()[0]
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+        assert int(np.argmax(a)) == int(np.argmax(b)) == 1 * 64 + 32

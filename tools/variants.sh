@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/variants.sh <steps> "<bench args>" lib1.so lib2.so ...   (run on the GPU box)
-# environment variables (e.g. HELICON_HIP_OVERLAP) pass through to bench.py
+# environment variables pass through to bench.py
 steps=$1; shift
 extra=$1; shift
 for lib in "$@"; do
