@@ -47,8 +47,8 @@
 #ifndef HH_KA_BAND
 #define HH_KA_BAND 64       // K_A: image columns per workgroup (N >= 256)
 #endif
-#ifndef HH_KB_BPW
-#define HH_KB_BPW 16       // K_B: ky blocks (of 8 rows) per workgroup
+#ifndef HH_KB_CPW
+#define HH_KB_CPW 16       // K_B: candidates per workgroup (one ky block of 8 rows of each)
 #endif
 #ifndef HH_KT_PAIRS
 #define HH_KT_PAIRS 32     // run-table first pass: column pairs per workgroup
@@ -344,15 +344,10 @@ struct RefConsts {
   double var_e;  // sum w (E-Ebar)^2
 };
 
-__device__ __forceinline__ float finalize_one(const double* __restrict__ partials, int nblk, int64_t i,
-                                              const RefConsts& rc) {
-  double s1 = 0, s2 = 0, s3 = 0;
-  for (int k = 0; k < nblk; ++k) {
-    const double* p = partials + (i * nblk + k) * 3;
-    s1 += p[0];
-    s2 += p[1];
-    s3 += p[2];
-  }
+// Pearson coefficient of one candidate from its partial moments: `team` lanes (a whole wavefront,
+// or the whole workgroup when it is smaller) stride over the npart slots, the sums are reduced in
+// float64 by shuffles, lane 0 of the team returns the score.
+__device__ __forceinline__ float pearson_from_moments(double s1, double s2, double s3, const RefConsts& rc) {
   double score = 0.0;
   if (rc.sw > 0) {
     const double var_q = s2 - s1 * s1 / rc.sw;
@@ -365,18 +360,70 @@ __device__ __forceinline__ float finalize_one(const double* __restrict__ partial
   return (float)score;
 }
 
-__global__ void k_finalize(const double* __restrict__ partials, int nblk, int64_t n, RefConsts rc,
-                           float* __restrict__ scores) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) scores[i] = finalize_one(partials, nblk, i, rc);
+__device__ __forceinline__ void team_moments(const double* __restrict__ partials, int npart, int64_t i, int lane,
+                                             int team, double& s1, double& s2, double& s3) {
+  s1 = s2 = s3 = 0;
+  for (int k = lane; k < npart; k += team) {
+    const double* p = partials + (i * npart + k) * 3;
+    s1 += p[0];
+    s2 += p[1];
+    s3 += p[2];
+  }
+  for (int off = team >> 1; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off, team);
+    s2 += __shfl_down(s2, off, team);
+    s3 += __shfl_down(s3, off, team);
+  }
 }
 
-struct FinArgs {  // finalize of the previous batch, folded into k_first_pass (n == 0: nothing to do)
+// scores[i] for i in [0, n): one team per candidate, teams_total teams in flight, this one is team_id
+__device__ __forceinline__ void finalize_range(const double* __restrict__ partials, int npart, int n,
+                                               const RefConsts& rc, float* __restrict__ scores, int team_id,
+                                               int teams_total, int lane, int team) {
+  for (int i = team_id; i < n; i += teams_total) {
+    double s1, s2, s3;
+    team_moments(partials, npart, i, lane, team, s1, s2, s3);
+    if (lane == 0) scores[i] = pearson_from_moments(s1, s2, s3, rc);
+  }
+}
+
+__global__ void k_finalize(const double* __restrict__ partials, int npart, int64_t n, RefConsts rc,
+                           float* __restrict__ scores) {
+  const int team = blockDim.x < 64 ? blockDim.x : 64;
+  const int per_block = blockDim.x / team;
+  finalize_range(partials, npart, (int)n, rc, scores, blockIdx.x * per_block + threadIdx.x / team,
+                 gridDim.x * per_block, threadIdx.x % team, team);
+}
+
+// sums of the partial moments per candidate ([n][3]) for the several-segment scorer
+__global__ void k_sum_partials(const double* __restrict__ partials, int npart, int n, double* __restrict__ sums) {
+  const int team = 64, per_block = blockDim.x / team;
+  const int lane = threadIdx.x % team;
+  for (int i = blockIdx.x * per_block + threadIdx.x / team; i < n; i += gridDim.x * per_block) {
+    double s1, s2, s3;
+    team_moments(partials, npart, i, lane, team, s1, s2, s3);
+    if (lane == 0) {
+      sums[3 * i] = s1;
+      sums[3 * i + 1] = s2;
+      sums[3 * i + 2] = s3;
+    }
+  }
+}
+
+struct FinArgs {  // scores of the previous batch, folded into the first pass as grid layer 0 (n == 0: none)
   const double* partials;
   float* scores;
-  int n, nblk;
+  int n, npart;
   RefConsts rc;
 };
+
+// the folded layer: every workgroup of grid layer 0 takes part, one team of lanes per candidate
+__device__ __forceinline__ void finalize_layer(const FinArgs& f) {
+  const int team = blockDim.x < 64 ? blockDim.x : 64;
+  const int per_block = blockDim.x / team;
+  finalize_range(f.partials, f.npart, f.n, f.rc, f.scores, blockIdx.x * per_block + threadIdx.x / team,
+                 gridDim.x * per_block, threadIdx.x % team, team);
+}
 
 // ------------------------------------------------------------------------------------------
 // K_A: raster (or image load) + column FFT.  A workgroup owns a band of image columns of one
@@ -547,7 +594,7 @@ __device__ __forceinline__ void fill_centres(float2* cent, const Cand& c, const 
 }
 
 template <int N, int MODE, bool RESIDENT>
-__device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand& c, int c_lo, int c_hi,
+__device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const size_t b, const Cand& c, int c_lo, int c_hi,
                                                  const TwLds& tw, float2* bufs, float2* cent) {
   using K = KA<N>;
   constexpr int T = K::T;
@@ -555,7 +602,6 @@ __device__ __forceinline__ void first_pass_tiles(const FirstArgs& a, const Cand&
   const int f = tid / T, t = tid % T;
   float2* const buf = bufs + f * K::BUF;
   const int band0 = blockIdx.x * K::BAND;
-  const size_t b = blockIdx.y;
   const DevGeom& g = a.g;
 #pragma unroll 1
   for (int tile = 0; tile < K::TPW; ++tile) {
@@ -633,17 +679,15 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
   const int f = tid / T, t = tid % T;
   float2* const buf = bufs + f * K::BUF;
   const int band0 = blockIdx.x * K::BAND;
-  const size_t b = blockIdx.y;
   const DevGeom& g = a.g;
 
   if constexpr (MODE == MODE_RASTER) {
-    if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {  // the extra layer: scores of the previous batch
-      if (blockIdx.x == 0)
-        for (int i = tid; i < a.fin.n; i += K::THREADS)
-          a.fin.scores[i] = finalize_one(a.fin.partials, a.fin.nblk, i, a.fin.rc);
+    if (a.fin.n > 0 && blockIdx.y == 0) {  // the extra layer: scores of the previous batch
+      finalize_layer(a.fin);
       return;
     }
   }
+  const size_t b = blockIdx.y - ((MODE == MODE_RASTER && a.fin.n > 0) ? 1 : 0);
 
   // Lattice centres that can reach this band of columns -> LDS, once per workgroup.  The axial
   // coordinate of centre (i, s, u) is m5 * i * rise + O(slack), so only a window of subunit
@@ -679,10 +723,10 @@ __global__ __launch_bounds__(KA<N>::THREADS, (N >= 512 ? HH_KA_WPS : 1)) void k_
   // Two copies of the tile loop: the common one never refills the centre list, so the float64
   // trigonometry of the refill cannot raise its register pressure.
   if (resident)
-    first_pass_tiles<N, MODE, true>(a, c, c_lo, c_hi, tw, bufs, cent);
+    first_pass_tiles<N, MODE, true>(a, b, c, c_lo, c_hi, tw, bufs, cent);
 #ifndef HH_NO_CHUNKED
   else
-    first_pass_tiles<N, MODE, false>(a, c, c_lo, c_hi, tw, bufs, cent);
+    first_pass_tiles<N, MODE, false>(a, b, c, c_lo, c_hi, tw, bufs, cent);
 #endif
 }
 
@@ -777,10 +821,8 @@ __global__ __launch_bounds__(256) void k_first_pass_table(TableArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* const lds_g = reinterpret_cast<float2*>(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {  // the extra layer: scores of the previous batch
-    if (blockIdx.x == 0)
-      for (int i = tid; i < a.fin.n; i += K::THREADS)
-        a.fin.scores[i] = finalize_one(a.fin.partials, a.fin.nblk, i, a.fin.rc);
+  if (a.fin.n > 0 && blockIdx.y == 0) {  // the extra layer: scores of the previous batch
+    finalize_layer(a.fin);
     return;
   }
   const int band = blockIdx.x % K::NQX, slice = blockIdx.x / K::NQX;
@@ -790,7 +832,7 @@ __global__ __launch_bounds__(256) void k_first_pass_table(TableArgs a) {
     const unsigned long long bits = K::KYW >= 512 ? ~0ull : ((1ull << (K::KYW / 8)) - 1ull) << (ky0 / 8);
     if (!(a.kb_mask & bits)) return;
   }
-  const size_t b = blockIdx.y;
+  const size_t b = blockIdx.y - (a.fin.n > 0 ? 1 : 0);
   const DevGeom& g = a.g;
   const Cand c = decode_candidate(a.params + 4 * b, g);
   const int run = (int)(b / (size_t)a.run_len);
@@ -904,11 +946,12 @@ struct SecondArgs {
   const float2* inter;    // [B] x line-blocked half spectrum (inter_index)
   const float2* twtab;    // [N]
   const float2* w2;       // [N/2+1][T][8] {w, w*(E-Ebar)} at kx = t + 64 m: a lane's 8 bins are contiguous (EPI_SCORE)
-  double* partials;       // [B][NBLK][3]                      (EPI_SCORE)
+  double* partials;       // [B][NPART][3]: moments per spectrum row (and wavefront of the row)  (EPI_SCORE)
   float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
   float* q_out;           // [B][N/2+1][N] masked q, natural order (EPI_QSTORE)
   const int* kb_list;     // ky blocks to process (ascending); NULL = all N/16 of them
   int n_kb;               // entries of kb_list (or N/16)
+  int batch;              // candidates in this launch
   int log_flag;
 };
 
@@ -921,16 +964,15 @@ struct KB {
   static constexpr int THREADS = GROUPS * T;  // == N
   static constexpr int ROWS = N / 2;
   static constexpr int NKB = ROWS / 8;        // ky blocks per candidate
-  static constexpr int BPW = NKB < HH_KB_BPW ? NKB : HH_KB_BPW;  // ky blocks per workgroup
-  static constexpr int RPW = 8 * BPW;         // rows per workgroup
-  static constexpr int NBLK = NKB / BPW;      // workgroups per candidate
+  static constexpr int CPW = HH_KB_CPW;       // candidates per workgroup (one ky block of each)
+  static constexpr int WPR = T > 64 ? T / 64 : 1;   // wavefronts per spectrum row
+  static constexpr int NPART = (ROWS + 1) * WPR;    // partial-moment slots per candidate: [ky 0..N/2][wavefront]
   static constexpr int BUF = N;               // complex slots per FFT exchange buffer
   static constexpr int PROW = N + 2;          // complex slots per panel row (+16 B: conflict-free b128 writes)
   static constexpr size_t LDS_PANEL = (size_t)8 * PROW * sizeof(float2);
   static constexpr size_t LDS_FFT = (size_t)GROUPS * BUF * sizeof(float2);
   static constexpr size_t LDS = LDS_PANEL + LDS_FFT + (HH_KB_TWLDS ? (size_t)(TwN<N>::lds_total + 1) * sizeof(float2) : 0);
   static constexpr int WAVES_PER_SIMD = HH_KB_WPS;  // register budget (512 / WPS VGPRs)
-  static_assert(NBLK * BPW == NKB, "row tiling");
 };
 
 // q = log1p(|F|) or |F| (transforms.py:807-810), up to a constant factor: the Pearson coefficient is
@@ -944,22 +986,49 @@ __device__ __forceinline__ float amp_to_q(float2 f) {
   return a;
 }
 
+// Sum over the TL = min(T, 64) lanes of a transform group inside one wavefront; every lane of the
+// group's first 16-lane row (in particular its lane 0) ends up with the total.  A full wavefront
+// uses DPP within the 16-lane rows and four scalar lane reads across them: no LDS traffic.
+template <int TL>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (TL == 64) {
+#define HH_DPP_ADD(CTRL) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true))
+    HH_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    HH_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    HH_DPP_ADD(0x141);  // row_half_mirror
+    HH_DPP_ADD(0x140);  // row_mirror: every lane of a row holds the row's sum
+#undef HH_DPP_ADD
+    const int iv = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+  } else {
+#pragma unroll
+    for (int off = TL / 2; off > 0; off >>= 1) v += __shfl_down(v, off, TL);
+    return v;
+  }
+}
+
+// A workgroup owns ONE ky block (8 spectrum rows, one per transform group) and walks CPW candidates:
+// the rows' mask weights and centred reference values are loaded once into registers and serve all
+// of them, so the second pass reads the weight table once per 16 candidates instead of once per
+// candidate (that re-read cost as much L2 -> CU traffic as the intermediate itself).  Each row's
+// three moments are reduced inside its wavefront and written as one partial triple.
 template <int N, int EPI, int LOG>
 __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD : 1)) void k_second_pass(SecondArgs a) {
   using K = KB<N>;
-  constexpr int T = K::T;
+  constexpr int T = K::T, TL = T < 64 ? T : 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* const panel = reinterpret_cast<float2*>(smem);
   float2* const bufs = reinterpret_cast<float2*>(smem + K::LDS_PANEL);
   const int tid = threadIdx.x;
-  const int gi = tid / T, t = tid % T;  // group gi owns row gi of every ky block
+  const int gi = tid / T, t = tid % T;  // group gi owns row gi of the ky block
   float2* const buf = bufs + gi * K::BUF;
-  const size_t b = blockIdx.y;
-  const float2* const in = a.inter + b * (size_t)K::ROWS * N;
-  // this workgroup's ky blocks: entries [first, first + nblk) of the (mask-filtered) block list
-  const int first = blockIdx.x * K::BPW;
-  const int nblk = min(K::BPW, a.n_kb - first);
-  auto block_of = [&](int i) { return a.kb_list ? a.kb_list[first + i] : first + i; };
+  const int kb = a.kb_list ? a.kb_list[blockIdx.x] : (int)blockIdx.x;
+  const int row = kb * 8 + gi;
+  const int c0 = blockIdx.y * K::CPW;
+  const int nc = min(K::CPW, a.batch - c0);
+  const size_t cand_stride = (size_t)K::ROWS * N;
+  const float2* const in0 = a.inter + (size_t)c0 * cand_stride + (size_t)kb * 8 * N;
 
 #if HH_KB_TWLDS
   float2* const twl = reinterpret_cast<float2*>(smem + K::LDS_PANEL + K::LDS_FFT);
@@ -971,14 +1040,39 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
   load_twiddles<N>(tw, t, a.twtab);
   const TwRegs twsrc{tw};
 #endif
-  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+
+  // this row's weights {w, w (E - Ebar)} for the lane's 8 bins; the packed row 0 carries ky = 0 and
+  // ky = N/2, so its group also keeps the weights of row N/2
+  float2 w[8], wn[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) w[m] = wn[m] = make_float2((HH_ABLATE & 64) ? 1.f : 0.f, (HH_ABLATE & 64) ? 0.5f : 0.f);
+  if constexpr (EPI != EPI_STORE) {
+    if (!(HH_ABLATE & 64)) {
+      const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + t) * 8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float4 q = wrow[m];
+        w[2 * m] = make_float2(q.x, q.y);
+        w[2 * m + 1] = make_float2(q.z, q.w);
+      }
+      if (row == 0) {
+        const float4* const nrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)(N / 2) * T + t) * 8);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float4 q = nrow[m];
+          wn[2 * m] = make_float2(q.x, q.y);
+          wn[2 * m + 1] = make_float2(q.z, q.w);
+        }
+      }
+    }
+  }
 
   // A ky block is N/2 lines = 4N 16-byte pieces, contiguous in memory: piece q = pair*8 + r holds
   // H[ky = 8 kb + r][x = 2 pair, 2 pair + 1].  Every thread moves 4 pieces (coalesced 16 B/lane).
   // (four named registers, not an array: hipcc puts a conditionally re-loaded float4 array in scratch)
   float4 ld0, ld1, ld2, ld3;
   {
-    const float4* src = reinterpret_cast<const float4*>(in + (size_t)block_of(0) * 8 * N) + tid;
+    const float4* src = reinterpret_cast<const float4*>(in0) + tid;
     ld0 = src[0];
     ld1 = src[K::THREADS];
     ld2 = src[2 * K::THREADS];
@@ -986,9 +1080,13 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
   }
   // piece q = i * THREADS + tid -> panel slot of (r = q % 8, pair = q / 8)
   auto slot = [&](int i) { const int q = i * K::THREADS + tid; return (q & 7) * K::PROW + 2 * (q >> 3); };
+  // one partial triple per (row, wavefront of the row); lane 0 of the group's wavefront writes it
+  const int wave_in_row = T > 64 ? (t >> 6) : 0;
+  const bool writer = (t & (TL - 1)) == 0;
 
 #pragma unroll 1
-  for (int blk = 0; blk < nblk; ++blk) {
+  for (int cc = 0; cc < nc; ++cc) {
+    const size_t b = (size_t)(c0 + cc);
     // transpose through LDS: panel[r][x]
     *reinterpret_cast<float4*>(panel + slot(0)) = ld0;
     *reinterpret_cast<float4*>(panel + slot(1)) = ld1;
@@ -998,123 +1096,100 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = panel[gi * K::PROW + t + m * T];
-    __syncthreads();  // the panel may be overwritten; the next block's loads fly under this FFT
-    if (blk + 1 < nblk) {
-      const float4* src = reinterpret_cast<const float4*>(in + (size_t)block_of(blk + 1) * 8 * N) + tid;
+    __syncthreads();  // the panel may be overwritten; the next candidate's loads fly under this FFT
+    if (cc + 1 < nc) {
+      const float4* src = reinterpret_cast<const float4*>(in0 + (size_t)(cc + 1) * cand_stride) + tid;
       ld0 = src[0];
       ld1 = src[K::THREADS];
       ld2 = src[2 * K::THREADS];
       ld3 = src[3 * K::THREADS];
     }
-    const int row = block_of(blk) * 8 + gi;
-    // this row's weights: 64 contiguous bytes per lane, requested before the FFT so the (L2) latency
-    // is covered by the butterflies
-    float4 wq0, wq1, wq2, wq3;
-    if constexpr (EPI != EPI_STORE) {
-      const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + t) * 8);
-      wq0 = wrow[0];
-      wq1 = wrow[1];
-      wq2 = wrow[2];
-      wq3 = wrow[3];
-    }
     if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
-    if (row == 0) continue;  // the packed row is un-packed after the loop
+
+    if (kb == 0 && (gi == 0 || T > 64)) {
+      // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]); un-pack it into the
+      // ky = 0 and ky = N/2 rows (all groups of a T > 64 workgroup take the barriers of the exchange).
+#pragma unroll
+      for (int m = 0; m < 8; ++m) buf[t + m * T] = v[m];  // every group into its own exchange buffer
+      group_sync<T>();
+      if (gi == 0) {
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int kx = t + m * T;
+          const float2 ck = v[m];
+          const float2 cm = buf[(N - kx) & (N - 1)];
+          const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
+          const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
+          if constexpr (EPI != EPI_STORE) {
+            const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
+            a1 += w[m].x * q0;
+            a2 += w[m].x * q0 * q0;
+            n1 += wn[m].x * qn;
+            n2 += wn[m].x * qn * qn;
+            if constexpr (EPI == EPI_QSTORE) {
+              float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
+              q0row[kx] = w[m].x > 0.f ? q0 : 0.f;
+              q0row[(size_t)(N / 2) * N + kx] = wn[m].x > 0.f ? qn : 0.f;
+            } else {
+              a3 += w[m].y * q0;
+              n3 += wn[m].y * qn;
+            }
+          } else {
+            float2* const so = a.spec_out + b * (size_t)(N / 2 + 1) * N;
+            so[kx] = f0;
+            so[(size_t)(N / 2) * N + kx] = fn;
+          }
+        }
+        if constexpr (EPI != EPI_STORE) {
+          a1 = group_sum<TL>(a1);
+          a2 = group_sum<TL>(a2);
+          a3 = group_sum<TL>(a3);
+          n1 = group_sum<TL>(n1);
+          n2 = group_sum<TL>(n2);
+          n3 = group_sum<TL>(n3);
+          if (writer) {
+            double* const o = a.partials + (b * K::NPART + wave_in_row) * 3;
+            o[0] = a1;
+            o[1] = a2;
+            o[2] = a3;
+            double* const on = a.partials + (b * K::NPART + (size_t)K::ROWS * K::WPR + wave_in_row) * 3;
+            on[0] = n1;
+            on[1] = n2;
+            on[2] = n3;
+          }
+        }
+      }
+      group_sync<T>();  // the mirror reads are done before the next transform's exchange writes
+      if (gi == 0) continue;
+    }
+
     if constexpr (EPI != EPI_STORE) {
-      const float2 w[8] = {make_float2(wq0.x, wq0.y), make_float2(wq0.z, wq0.w), make_float2(wq1.x, wq1.y),
-                           make_float2(wq1.z, wq1.w), make_float2(wq2.x, wq2.y), make_float2(wq2.z, wq2.w),
-                           make_float2(wq3.x, wq3.y), make_float2(wq3.z, wq3.w)};
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
       float* const qrow = (EPI == EPI_QSTORE) ? a.q_out + (b * (size_t)(N / 2 + 1) + row) * N : nullptr;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
-        const float wx = (HH_ABLATE & 64) ? 1.f : w[m].x, wy = (HH_ABLATE & 64) ? 0.5f : w[m].y;
-        s1 += wx * q;
-        s2 += wx * q * q;
+        s1 += w[m].x * q;
+        s2 += w[m].x * q * q;
         if constexpr (EPI == EPI_QSTORE)
-          qrow[t + m * T] = wx > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
+          qrow[t + m * T] = w[m].x > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
         else
-          s3 += wy * q;
+          s3 += w[m].y * q;
+      }
+      s1 = group_sum<TL>(s1);
+      s2 = group_sum<TL>(s2);
+      s3 = group_sum<TL>(s3);
+      if (writer) {
+        double* const o = a.partials + (b * K::NPART + (size_t)row * K::WPR + wave_in_row) * 3;
+        o[0] = s1;
+        o[1] = s2;
+        o[2] = s3;
       }
     } else {
       float2* const so = a.spec_out + (b * (size_t)(N / 2 + 1) + row) * N;
 #pragma unroll
       for (int m = 0; m < 8; ++m) so[t + m * T] = v[m];
-    }
-  }
-
-  // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]); un-pack it into the
-  // ky = 0 and ky = N/2 rows.  Done once per candidate, outside the row loop, by the first
-  // transform group of workgroup 0 (all lanes of a T > 64 group's workgroup take the barriers).
-  if (blockIdx.x == 0 && (gi == 0 || T > 64)) {
-    float2 v[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int x = t + m * T;
-      v[m] = in[inter_index<N>(0, x >> 1) + (x & 1)];
-    }
-    fft_lanes<N>(v, twsrc, t, buf);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) buf[t + m * T] = v[m];
-    group_sync<T>();
-    if (gi == 0) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int kx = t + m * T;
-        const float2 ck = v[m];
-        const float2 cm = buf[(N - kx) & (N - 1)];
-        const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
-        const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
-        if constexpr (EPI != EPI_STORE) {
-          const float2 w0 = a.w2[(size_t)t * 8 + m];
-          const float2 wn = a.w2[((size_t)(N / 2) * T + t) * 8 + m];
-          const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
-          s1 += w0.x * q0 + wn.x * qn;
-          s2 += w0.x * q0 * q0 + wn.x * qn * qn;
-          if constexpr (EPI == EPI_QSTORE) {
-            float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
-            q0row[kx] = w0.x > 0.f ? q0 : 0.f;
-            q0row[(size_t)(N / 2) * N + kx] = wn.x > 0.f ? qn : 0.f;
-          } else {
-            s3 += w0.y * q0 + wn.y * qn;
-          }
-        } else {
-          float2* const so = a.spec_out + b * (size_t)(N / 2 + 1) * N;
-          so[kx] = f0;
-          so[(size_t)(N / 2) * N + kx] = fn;
-        }
-      }
-    }
-  }
-
-  if constexpr (EPI != EPI_STORE) {
-    // float partials (<= 64 terms per lane) -> float64 wave shuffle reduce -> LDS -> one triple
-    double d1 = s1, d2 = s2, d3 = s3;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      d1 += __shfl_down(d1, off, 64);
-      d2 += __shfl_down(d2, off, 64);
-      d3 += __shfl_down(d3, off, 64);
-    }
-    __syncthreads();
-    double* const red = reinterpret_cast<double*>(smem);
-    constexpr int NW = (K::THREADS + 63) / 64;
-    if ((tid & 63) == 0) {
-      red[3 * (tid >> 6)] = d1;
-      red[3 * (tid >> 6) + 1] = d2;
-      red[3 * (tid >> 6) + 2] = d3;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double r1 = 0, r2 = 0, r3 = 0;
-      for (int w = 0; w < NW; ++w) {
-        r1 += red[3 * w];
-        r2 += red[3 * w + 1];
-        r3 += red[3 * w + 2];
-      }
-      double* const o = a.partials + (b * gridDim.x + blockIdx.x) * 3;
-      o[0] = r1;
-      o[1] = r2;
-      o[2] = r3;
     }
   }
 }
@@ -1373,7 +1448,8 @@ struct hh_ctx {
 
   float2* d_tw = nullptr;
   float2* d_inter = nullptr;     // [max_batch][N/2][N]
-  double* d_partials = nullptr;  // [max_batch][NBLK][3]
+  double* d_partials = nullptr;  // [max_batch][NPART][3], zero where the mask skips a ky block
+  double* d_psum = nullptr;      // S > 1: [max_batch][3] summed partials
   double* d_params = nullptr;    // staging for hh_sweep
   float* d_scores = nullptr;
   int64_t cap_params = 0;
@@ -1427,25 +1503,14 @@ int fail(hh_ctx* c, int code, const std::string& msg) {
 
 bool supported_n(int n) { return n == 32 || n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
 
-int bpw_for(int n) {
+int npart_for(int n) {  // partial-moment slots per candidate (KB<N>::NPART)
   switch (n) {
-    case 32: return KB<32>::BPW;
-    case 64: return KB<64>::BPW;
-    case 128: return KB<128>::BPW;
-    case 256: return KB<256>::BPW;
-    case 512: return KB<512>::BPW;
-    default: return KB<1024>::BPW;
-  }
-}
-
-int nblk_for(int n) {
-  switch (n) {
-    case 32: return KB<32>::NBLK;
-    case 64: return KB<64>::NBLK;
-    case 128: return KB<128>::NBLK;
-    case 256: return KB<256>::NBLK;
-    case 512: return KB<512>::NBLK;
-    default: return KB<1024>::NBLK;
+    case 32: return KB<32>::NPART;
+    case 64: return KB<64>::NPART;
+    case 128: return KB<128>::NPART;
+    case 256: return KB<256>::NPART;
+    case 512: return KB<512>::NPART;
+    default: return KB<1024>::NPART;
   }
 }
 
@@ -1494,8 +1559,10 @@ int launch_second(hh_ctx* c, const SecondArgs& a, int batch) {
     attr_done = true;
   }
   ProfScope ps(c, 1);
-  const int grid_x = (a.n_kb + K::BPW - 1) / K::BPW;
-  hipLaunchKernelGGL((k_second_pass<N, EPI, LOG>), dim3(grid_x, batch), dim3(K::THREADS), K::LDS, c->stream, a);
+  SecondArgs args = a;
+  args.batch = batch;
+  hipLaunchKernelGGL((k_second_pass<N, EPI, LOG>), dim3(a.n_kb, (batch + K::CPW - 1) / K::CPW), dim3(K::THREADS),
+                     K::LDS, c->stream, args);
   HH_HIP(c, hipGetLastError());
   return HH_OK;
 }
@@ -1685,7 +1752,8 @@ RunPlan plan_runs(hh_ctx* c, const double* hp, int64_t g) {
 }
 
 // Second pass + scores of one batch whose intermediate is in c->d_inter.
-int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, int nblk, float* d_scores, FinArgs& pending) {
+int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinArgs& pending) {
+  const int npart = npart_for(c->n);
   SecondArgs sa{};
   sa.inter = c->d_inter;
   sa.twtab = c->d_tw;
@@ -1700,11 +1768,12 @@ int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, int nblk, float*
     if (rc) return rc;
     float* const out = d_scores + g0;
     if (g0 + nb < g) {
-      pending = FinArgs{c->d_partials, out, nb, nblk, c->ref[0]};
+      pending = FinArgs{c->d_partials, out, nb, npart, c->ref[0]};
     } else {
       ProfScope ps(c, 2);
-      hipLaunchKernelGGL(k_finalize, dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
-                         (int64_t)nb, c->ref[0], out);
+      const int threads = c->n < 64 ? c->n : 256;  // teams of min(64, n) lanes, one candidate each
+      hipLaunchKernelGGL(k_finalize, dim3(std::min(1024, (nb + 3) / 4)), dim3(threads), 0, c->stream, c->d_partials,
+                         npart, (int64_t)nb, c->ref[0], out);
     }
     HH_HIP(c, hipGetLastError());
   } else {
@@ -1719,7 +1788,9 @@ int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, int nblk, float*
     hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
                        c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
     const int total = nb * c->n_segments;
-    hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblk,
+    hipLaunchKernelGGL(k_sum_partials, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, c->stream, c->d_partials, npart,
+                       nb, c->d_psum);
+    hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_psum, 1,
                        c->d_cpart, rows, c->b_pad, c->s_pad, nb, c->n_segments, c->d_ref, d_scores, g, g0);
     HH_HIP(c, hipGetLastError());
   }
@@ -1729,7 +1800,6 @@ int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, int nblk, float*
 // The sweep with the shared-twist first pass (plan.ok): batches are whole runs (or pieces of one
 // run); the tables of as many runs as fit HH_TABLE_BYTES_MAX are built by one launch ahead of them.
 int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const RunPlan& plan) {
-  const int nblk = (c->n_kb + bpw_for(c->n) - 1) / bpw_for(c->n);
   const int64_t runs = g / plan.len;
   const int nky = c->n / 2;
   const int64_t per_batch = plan.len <= c->max_batch ? c->max_batch / plan.len : 1;
@@ -1794,7 +1864,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
         int rc = dispatch_first_table(c, ta, nb);
         if (rc) return rc;
         pending = FinArgs{};
-        rc = second_and_scores(c, g, g0, nb, nblk, d_scores, pending);
+        rc = second_and_scores(c, g, g0, nb, d_scores, pending);
         if (rc) return rc;
       }
     }
@@ -1807,7 +1877,6 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
   const RunPlan plan = plan_runs(c, h_params, g);
   c->last_first_pass = plan.ok ? 1 : 0;
   if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan);
-  const int nblk = (c->n_kb + bpw_for(c->n) - 1) / bpw_for(c->n);  // K_B workgroups per candidate
   FinArgs pending{};
   int64_t batch_no = 0;
   for (int64_t g0 = 0; g0 < g; g0 += c->max_batch, ++batch_no) {
@@ -1825,7 +1894,7 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
     if (rc) return rc;
     pending = FinArgs{};
-    rc = second_and_scores(c, g, g0, nb, nblk, d_scores, pending);
+    rc = second_and_scores(c, g, g0, nb, d_scores, pending);
     if (rc) return rc;
   }
   c->prof_now = false;
@@ -1959,7 +2028,9 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   c->stream = c->own_stream;
   HH_CREATE_HIP(hipMalloc(&c->d_tw, (size_t)n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
-  HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)max_batch * nblk_for(n) * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)max_batch * npart_for(n) * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMemset(c->d_partials, 0, (size_t)max_batch * npart_for(n) * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMalloc(&c->d_psum, (size_t)max_batch * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
 
   std::vector<float2> tw((size_t)n);
@@ -1984,6 +2055,7 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_tw);
   (void)hipFree(c->d_inter);
   (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_psum);
   (void)hipFree(c->d_params);
   (void)hipFree(c->d_scores);
   (void)hipFree(c->d_units);
@@ -2181,6 +2253,8 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   c->d_kb_list = nullptr;
   HH_HIP(c, hipMalloc(&c->d_kb_list, kb_list.size() * sizeof(int)));
   HH_HIP(c, hipMemcpyAsync(c->d_kb_list, kb_list.data(), kb_list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // rows of skipped ky blocks keep zero moments
+  HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)c->max_batch * npart_for(n) * 3 * sizeof(double), c->stream));
   c->n_kb = (int)kb_list.size();
   c->kb_mask = kb_mask;
   c->s_pad = s_pad;
