@@ -84,9 +84,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--first-pass", default="auto", choices=["auto", "transform"],
-                    help="auto: run tables on twist-major grids (the default of the library); "
-                         "transform: raster + column transform for every candidate")
+    ap.add_argument("--first-pass", default="auto", choices=["auto", "tables", "transform"],
+                    help="auto: the library's choice (fused pass on twist-major grids); tables: run tables + "
+                         "second pass through the HBM intermediate; transform: raster + two transforms per candidate")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,9 +135,8 @@ def main():
     eng.set_stream(stream.cuda_stream)
     d_params = torch.from_numpy(grid.params).to(dev)
     d_scores = torch.empty((1, g_local), dtype=torch.float32, device=dev)
-    h_params = grid.params if args.first_pass == "auto" else None  # the host mirror lets the library see the runs
-    if args.first_pass != "auto":
-        eng.set_table_path(False)
+    h_params = grid.params if args.first_pass != "transform" else None  # the host mirror lets the library see the runs
+    eng.set_table_path({"auto": 2, "tables": 1, "transform": 0}[args.first_pass])
 
     def step():
         eng.sweep_device(d_params.data_ptr(), g_local, d_scores.data_ptr(), host_params=h_params)
@@ -246,6 +245,8 @@ def roofline(prof, n, b_alg):
             measured = {}
     kernels = {}
     for name, (ms, launches, bytes_per_cand, what) in per.items():
+        if launches == 0:  # the fused pass has no separate first pass
+            continue
         per_launch = cand / launches
         avg_us = 1e3 * ms / launches
         gbps = bytes_per_cand * per_launch / (avg_us * 1e-6) / 1e9
@@ -264,7 +265,7 @@ def roofline(prof, n, b_alg):
         "bound": "hbm", "kernel": "k_first_pass + k_second_pass (two-pass pipeline, per batch)",
         "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9),
         "traffic": traffic, "alg_bytes_per_candidate": b_alg,
-        "candidates_per_launch": cand / prof["n_first_pass"], "device_ms_sampled": device_ms,
+        "candidates_per_launch": cand / max(prof["n_first_pass"], prof["n_second_pass"]), "device_ms_sampled": device_ms,
         "run_table_ms_per_sweep": (prof["ms_centres"] / prof["n_centres"]) if prof["n_centres"] else None,
         "kernels": kernels,
     }

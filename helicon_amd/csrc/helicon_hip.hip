@@ -33,7 +33,8 @@
 #ifndef HH_ABLATE
 #define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads,
                            // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads; run-table first pass:
-                           // 128 no stores, 256 no accumulation, 1024 no table staging
+                           // 128 no stores, 256 no accumulation, 1024 no table staging; fused pass: 2048 no panel
+                           // accumulation, 4096 no column-factor prefetch (16 / 32 as for K_B)
 #endif
 #ifndef HH_KA_WPS
 #define HH_KA_WPS 8        // K_A: waves per SIMD the register allocator must leave room for (4 workgroups per CU)
@@ -55,6 +56,12 @@
 #endif
 #ifndef HH_KT_KYW
 #define HH_KT_KYW 128      // run-table first pass: ky rows per workgroup
+#endif
+#ifndef HH_KF_CPW
+#define HH_KF_CPW 16       // fused pass: candidates per workgroup
+#endif
+#ifndef HH_KF_WPS
+#define HH_KF_WPS 4        // fused pass: waves per SIMD the register allocator must leave room for
 #endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
@@ -1195,6 +1202,315 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused pass for shared-twist runs: the intermediate never leaves the compute unit.
+//   H[ky][x] = sum_c ex_c(x) G_c[ky]   (k_first_pass_table's identity)
+// needs, for one ky block (8 rows), only the 8-ky slice of the run's table (rows x 64 B, a few KB)
+// and the candidate's column factors ex_c(x).  A workgroup therefore owns one ky block of up to
+// CPW candidates of one run: it keeps the table slice in LDS (transposed, [ky][row]), builds each
+// candidate's 8 x N panel of H straight into the row transforms' exchange buffers, and runs
+// k_second_pass's transform + moments on it.  HBM sees the parameters, the column factors
+// (k_column_factors: KG x N floats per candidate, written once, read from L2) and the scores.
+// ------------------------------------------------------------------------------------------
+struct FactorArgs {
+  const double* params;   // [B][4]
+  const double* units;
+  const int* run_imax;    // [runs]
+  float* eg;              // [B][kg][N] column factors: eg[k][x] = ex of table row cg(x/4) + k at column x
+  int* cgs;               // [B][N/4] first table row of every group of four columns
+  int run_len, kg, rows_lds;
+  int count;              // candidates (0: nothing to do)
+  DevGeom g;
+};
+
+template <int N>
+__device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b) {
+  const int x = threadIdx.x;
+  const DevGeom& g = a.g;
+  const Cand c = decode_candidate(a.params + 4 * (size_t)b, g);
+  const int imax_t = a.run_imax[b / a.run_len];
+  const int rows = (2 * imax_t + 1) * g.n_units;
+  const float rp = (float)g.rpx;
+  const float k2 = g.inv_sigma2 * 1.44269504088896341f;
+  const int x0 = x & ~3;
+  // first subunit index whose footprint can reach the group's columns (axial coordinate z_u + i rise;
+  // the slack covers |z_u| and the float32 roundings)
+  int cg = 0;
+  if (c.M > 0) {
+    const float lo = ((float)(x0 - N / 2) * g.apix - rp * g.apix - g.slack) / (float)c.rise;
+    const int i0 = max(-c.imax, (int)ceilf(fmaxf(lo, -2.0e9f)));
+    cg = (min(i0, c.imax) + imax_t) * g.n_units;
+  }
+  cg = max(0, min(cg, a.rows_lds - a.kg));
+  for (int k = 0; k < a.kg; ++k) {
+    const int r = cg + k;
+    int i = r - imax_t, u = 0;
+    if (g.n_units > 1) {
+      i = r / g.n_units - imax_t;
+      u = r % g.n_units;
+    }
+    float wgt = 0.f;
+    if (r < rows && i >= -c.imax && i <= c.imax) {
+      const float xc = (float)a.units[3 * u + 2] + (float)((double)i * c.rise);  // utils.py:160, float32
+      const float cx = xc * g.inv_apix + (float)(N / 2);
+      const float dx = (float)(x - N / 2) * g.apix - xc;
+      if (fabsf((float)x - cx) <= rp) wgt = __builtin_amdgcn_exp2f(-dx * dx * k2);
+    }
+    a.eg[((size_t)b * a.kg + k) * N + x] = wgt;
+  }
+  if ((x & 3) == 0) a.cgs[(size_t)b * (N / 4) + (x >> 2)] = cg;
+}
+
+template <int N>
+__global__ __launch_bounds__(N) void k_column_factors(FactorArgs a) {
+  column_factors_of<N>(a, blockIdx.x);
+}
+
+struct FusedArgs {
+  const double* params;
+  const float2* twtab;
+  const float2* table;    // [runs][cap][N/2]
+  const int* run_imax;    // [runs]
+  const float* eg;        // [B][kg][N]
+  const int* cgs;         // [B][N/4]
+  const float2* w2;
+  double* partials;
+  float* q_out;           // EPI_QSTORE
+  const int* kb_list;
+  int n_kb;
+  int batch;              // candidates in this launch
+  int run_len;            // candidates per run inside this batch
+  int groups_per_run;     // workgroup layers per run: ceil(run_len / CPW)
+  int cap;                // table rows reserved per run
+  int rows_lds;           // table rows staged per ky (>= every run's row count, >= kg)
+  int kg;                 // table rows per group of four columns
+  int n_units;
+  int factor_layers;      // leading grid layers that compute the NEXT batch's column factors (next.count of them)
+  FinArgs fin;
+  FactorArgs next;
+};
+
+template <int N>
+struct KF {
+  static constexpr int T = N / 8;
+  static constexpr int THREADS = N;
+  static constexpr int CPW = HH_KF_CPW;            // candidates per workgroup
+  static constexpr int BROW = N + 4;               // complex slots per panel row (+32 B against bank conflicts)
+  static constexpr size_t LDS_BUF = (size_t)8 * BROW * sizeof(float2);
+  static size_t lds(int rows_lds, int kg) {
+    return LDS_BUF + (size_t)8 * rows_lds * sizeof(float2) + 2 * ((size_t)kg * N * sizeof(float) + (size_t)(N / 4) * sizeof(int));
+  }
+};
+
+template <int N, int EPI, int LOG>
+__global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(FusedArgs a) {
+  using K = KF<N>;
+  using KP = KB<N>;  // the partial-moment layout is k_second_pass's
+  constexpr int T = K::T, TL = T < 64 ? T : 64, NKY = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* const bufs = reinterpret_cast<float2*>(smem);
+  float2* const gs = reinterpret_cast<float2*>(smem + K::LDS_BUF);                       // [8][rows_lds]
+  float* const eg = reinterpret_cast<float*>(smem + K::LDS_BUF + (size_t)8 * a.rows_lds * sizeof(float2));  // [2][kg][N]
+  int* const cgs = reinterpret_cast<int*>(eg + (size_t)2 * a.kg * N);                    // [2][N/4]
+  const int tid = threadIdx.x;
+  // leading grid layers: the next batch's column factors (so that batch needs no launch of its own),
+  // then the scores of the previous batch
+  if ((int)blockIdx.y < a.factor_layers) {
+    const int cand = blockIdx.y * gridDim.x + blockIdx.x;
+    if (cand < a.next.count) column_factors_of<N>(a.next, cand);
+    return;
+  }
+  if (a.fin.n > 0 && (int)blockIdx.y == a.factor_layers) {
+    finalize_layer(a.fin);
+    return;
+  }
+  const int gi = tid / T, t = tid % T;
+  float2* const buf = bufs + gi * K::BROW;
+  const int gy = blockIdx.y - a.factor_layers - (a.fin.n > 0 ? 1 : 0);
+  const int kb = a.kb_list ? a.kb_list[blockIdx.x] : (int)blockIdx.x;
+  const int row = kb * 8 + gi;
+  const int run = gy / a.groups_per_run;
+  const int off = (gy % a.groups_per_run) * K::CPW;
+  const int cfirst = run * a.run_len + off;
+  const int nc = min(K::CPW, min(a.run_len - off, a.batch - cfirst));
+  if (nc <= 0) return;
+
+  float2 tw[TwN<N>::total];
+  load_twiddles<N>(tw, t, a.twtab);
+  const TwRegs twsrc{tw};
+
+  float2 w[8];  // this row's weights {w, w (E - Ebar)} for the lane's 8 bins, kept for all candidates
+  {
+    const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + t) * 8);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float4 q = wrow[m];
+      w[2 * m] = make_float2(q.x, q.y);
+      w[2 * m + 1] = make_float2(q.z, q.w);
+    }
+  }
+
+  // the run's table slice of this ky block, transposed to [ky in block][table row]; rows past the
+  // run's own count are zero
+  {
+    const int rows = (2 * a.run_imax[run] + 1) * a.n_units;
+    const float2* const tab = a.table + (size_t)run * a.cap * NKY + 8 * kb;
+    for (int e = tid; e < a.rows_lds * 4; e += K::THREADS) {
+      const int cr = e >> 2, part = e & 3;
+      const float4 q = *reinterpret_cast<const float4*>(tab + (size_t)min(cr, rows - 1) * NKY + 2 * part);
+      const bool in = cr < rows;
+      gs[(2 * part) * a.rows_lds + cr] = in ? make_float2(q.x, q.y) : make_float2(0.f, 0.f);
+      gs[(2 * part + 1) * a.rows_lds + cr] = in ? make_float2(q.z, q.w) : make_float2(0.f, 0.f);
+    }
+  }
+  // column factors of the first candidate (later ones are fetched under the previous transform)
+  const int n_e4 = a.kg * (N / 4);  // float4 pieces of one candidate's factors
+  auto stage_factors = [&](int b) {
+    const float4* const src = reinterpret_cast<const float4*>(a.eg + (size_t)b * a.kg * N);
+    for (int e = tid; e < n_e4; e += K::THREADS) reinterpret_cast<float4*>(eg)[e] = src[e];
+    if (tid < N / 4) cgs[tid] = a.cgs[(size_t)b * (N / 4) + tid];
+  };
+  stage_factors(cfirst);  // buffer 0
+  __syncthreads();
+
+  const int wave_in_row = T > 64 ? (t >> 6) : 0;
+  const bool writer = (t & (TL - 1)) == 0;
+
+#pragma unroll 1
+  for (int cc = 0; cc < nc; ++cc) {
+    const size_t b = (size_t)(cfirst + cc);
+    const int cur = cc & 1;
+    const float* const egc = eg + (size_t)cur * a.kg * N;
+    const int* const cgc = cgs + cur * (N / 4);
+    // next candidate's column factors: the loads fly under this candidate's panel build
+    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+    int ncg = 0;
+    const bool more = cc + 1 < nc && !(HH_ABLATE & 4096);
+    if (more) {
+      const float4* const src = reinterpret_cast<const float4*>(a.eg + (b + 1) * a.kg * N);
+      nx0 = src[min(tid, n_e4 - 1)];
+      nx1 = src[min(tid + K::THREADS, n_e4 - 1)];
+      nx2 = src[min(tid + 2 * K::THREADS, n_e4 - 1)];
+      nx3 = src[min(tid + 3 * K::THREADS, n_e4 - 1)];
+      ncg = a.cgs[(b + 1) * (N / 4) + min(tid, N / 4 - 1)];
+    }
+    // ---- this group's row of H, built by the group itself into its own exchange buffer (no
+    // workgroup barrier): a lane takes four consecutive columns at a time
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int xg = t + pass * T;
+      const float2* const grow = gs + gi * a.rows_lds + cgc[xg];
+      const float* const erow = egc + 4 * xg;
+      float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      for (int k = 0; k < ((HH_ABLATE & 2048) ? 0 : a.kg); ++k) {
+        const float2 gk = grow[k];
+        const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * N);
+        acc0.x = fmaf(e4.x, gk.x, acc0.x);
+        acc0.y = fmaf(e4.x, gk.y, acc0.y);
+        acc1.x = fmaf(e4.y, gk.x, acc1.x);
+        acc1.y = fmaf(e4.y, gk.y, acc1.y);
+        acc2.x = fmaf(e4.z, gk.x, acc2.x);
+        acc2.y = fmaf(e4.z, gk.y, acc2.y);
+        acc3.x = fmaf(e4.w, gk.x, acc3.x);
+        acc3.y = fmaf(e4.w, gk.y, acc3.y);
+      }
+      float4* const dst = reinterpret_cast<float4*>(buf + 4 * xg);
+      dst[0] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+      dst[1] = make_float4(acc2.x, acc2.y, acc3.x, acc3.y);
+    }
+    group_sync<T>();
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
+    if constexpr (T > 64) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
+    if (more) {  // into the other factor buffer: nobody reads it before the barrier at the end of this iteration
+      float4* const dst = reinterpret_cast<float4*>(eg + (size_t)(cur ^ 1) * a.kg * N);
+      if (tid < n_e4) dst[tid] = nx0;
+      if (tid + K::THREADS < n_e4) dst[tid + K::THREADS] = nx1;
+      if (tid + 2 * K::THREADS < n_e4) dst[tid + 2 * K::THREADS] = nx2;
+      if (tid + 3 * K::THREADS < n_e4) dst[tid + 3 * K::THREADS] = nx3;
+      if (tid < N / 4) cgs[(cur ^ 1) * (N / 4) + tid] = ncg;
+    }
+    if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
+
+    bool scored = false;
+    if (kb == 0 && (gi == 0 || T > 64)) {
+      // Row 0 of H packs two real sequences (see k_second_pass): un-pack into ky = 0 and ky = N/2
+#pragma unroll
+      for (int m = 0; m < 8; ++m) buf[t + m * T] = v[m];
+      group_sync<T>();
+      if (gi == 0) {
+        // the packed row also carries ky = N/2: its weights come from L2 here (one wavefront in 256)
+        const float2* const nrow = a.w2 + ((size_t)(N / 2) * T + t) * 8;
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float2 wnm = nrow[m];
+          const int kx = t + m * T;
+          const float2 ck = v[m];
+          const float2 cm = buf[(N - kx) & (N - 1)];
+          const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
+          const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
+          const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
+          a1 += w[m].x * q0;
+          a2 += w[m].x * q0 * q0;
+          n1 += wnm.x * qn;
+          n2 += wnm.x * qn * qn;
+          if constexpr (EPI == EPI_QSTORE) {
+            float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
+            q0row[kx] = w[m].x > 0.f ? q0 : 0.f;
+            q0row[(size_t)(N / 2) * N + kx] = wnm.x > 0.f ? qn : 0.f;
+          } else {
+            a3 += w[m].y * q0;
+            n3 += wnm.y * qn;
+          }
+        }
+        a1 = group_sum<TL>(a1);
+        a2 = group_sum<TL>(a2);
+        a3 = group_sum<TL>(a3);
+        n1 = group_sum<TL>(n1);
+        n2 = group_sum<TL>(n2);
+        n3 = group_sum<TL>(n3);
+        if (writer) {
+          double* const o = a.partials + (b * KP::NPART + wave_in_row) * 3;
+          o[0] = a1;
+          o[1] = a2;
+          o[2] = a3;
+          double* const on = a.partials + (b * KP::NPART + (size_t)KP::ROWS * KP::WPR + wave_in_row) * 3;
+          on[0] = n1;
+          on[1] = n2;
+          on[2] = n3;
+        }
+        scored = true;
+      }
+    }
+    if (!scored) {
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      float* const qrow = (EPI == EPI_QSTORE) ? a.q_out + (b * (size_t)(N / 2 + 1) + row) * N : nullptr;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
+        s1 += w[m].x * q;
+        s2 += w[m].x * q * q;
+        if constexpr (EPI == EPI_QSTORE)
+          qrow[t + m * T] = w[m].x > 0.f ? q : 0.f;
+        else
+          s3 += w[m].y * q;
+      }
+      s1 = group_sum<TL>(s1);
+      s2 = group_sum<TL>(s2);
+      s3 = group_sum<TL>(s3);
+      if (writer) {
+        double* const o = a.partials + (b * KP::NPART + (size_t)row * KP::WPR + wave_in_row) * 3;
+        o[0] = s1;
+        o[1] = s2;
+        o[2] = s3;
+      }
+    }
+    __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Several experimental segments against one candidate grid (BASELINE config 5): the covariance
 // numerators S3[s][c] = sum_k WEC[s][k] * Q[c][k] are a dense contraction over the K = (N/2+1) N
 // half-plane bins, so they run on the matrix cores with the exact-f32 MFMA (32x32x2, f32 in /
@@ -1448,7 +1764,8 @@ struct hh_ctx {
 
   float2* d_tw = nullptr;
   float2* d_inter = nullptr;     // [max_batch][N/2][N]
-  double* d_partials = nullptr;  // [max_batch][NPART][3], zero where the mask skips a ky block
+  double* d_partials = nullptr;  // [2][max_batch][NPART][3], zero where the mask skips a ky block; the halves alternate
+                                 // between batches (the fused pass scores batch i-1 while it writes batch i)
   double* d_psum = nullptr;      // S > 1: [max_batch][3] summed partials
   double* d_params = nullptr;    // staging for hh_sweep
   float* d_scores = nullptr;
@@ -1467,6 +1784,10 @@ struct hh_ctx {
   int64_t cap_runs = 0;
   std::vector<int> h_run_imax;
   int table_path = 1;            // 0: never take the shared-twist first pass
+  int fused_path = 1;            // 0: shared-twist runs go through the two-pass pipeline (k_first_pass_table + k_second_pass)
+  float* d_eg = nullptr;         // fused pass: [max_batch][kg][N] column factors
+  int* d_cgs = nullptr;          // fused pass: [max_batch][N/4]
+  size_t cap_eg = 0;
   int last_first_pass = 0;       // what the last sweep ran: 0 per-candidate transform, 1 run tables
   unsigned long long kb_mask = ~0ull;
   int s_pad = 0, b_pad = 0;
@@ -1513,6 +1834,17 @@ int npart_for(int n) {  // partial-moment slots per candidate (KB<N>::NPART)
     default: return KB<1024>::NPART;
   }
 }
+
+#define HH_SWITCH_N(c, CALL)                                        \
+  switch ((c)->n) {                                                 \
+    case 32: return CALL(32);                                       \
+    case 64: return CALL(64);                                       \
+    case 128: return CALL(128);                                     \
+    case 256: return CALL(256);                                     \
+    case 512: return CALL(512);                                     \
+    case 1024: return CALL(1024);                                   \
+  }                                                                 \
+  return fail(c, HH_ERR_ARG, "unsupported image size")
 
 struct ProfScope {  // hipEvent pair around one launch when profiling is on
   hh_ctx* c;
@@ -1666,16 +1998,7 @@ int launch_first_table(hh_ctx* c, const TableArgs& a, int batch) {
   return HH_OK;
 }
 
-#define HH_SWITCH_N(c, CALL)                                        \
-  switch ((c)->n) {                                                 \
-    case 32: return CALL(32);                                       \
-    case 64: return CALL(64);                                       \
-    case 128: return CALL(128);                                     \
-    case 256: return CALL(256);                                     \
-    case 512: return CALL(512);                                     \
-    case 1024: return CALL(1024);                                   \
-  }                                                                 \
-  return fail(c, HH_ERR_ARG, "unsupported image size")
+
 
 int dispatch_run_table(hh_ctx* c, const TableArgs& a, int runs, int rows) {
 #define HH_CALL(NN) launch_run_table<NN>(c, a, runs, rows)
@@ -1696,11 +2019,25 @@ struct RunPlan {
   bool ok = false;
   int64_t len = 0;
   int rows = 0;      // table rows per run: (2 max imax + 1) * n_units
-  int rows_lds = 0;  // table rows a band of image columns can need (from the smallest rise)
+  int rows_lds = 0;  // table rows a band of image columns can need (from the smallest rise); 0: too many
+  bool fused = false;  // the fused pass fits: whole table slice + column factors in LDS
+  int kg = 0;          // fused: table rows per group of four columns
+  int rows_f = 0;      // fused: table rows staged per ky
 };
 
 constexpr int64_t HH_MIN_RUN = 32;             // shorter runs do not amortise their table
 constexpr size_t HH_TABLE_BYTES_MAX = 1ull << 30;
+
+size_t fused_lds(int n, int rows_lds, int kg) {
+  switch (n) {
+    case 32: return KF<32>::lds(rows_lds, kg);
+    case 64: return KF<64>::lds(rows_lds, kg);
+    case 128: return KF<128>::lds(rows_lds, kg);
+    case 256: return KF<256>::lds(rows_lds, kg);
+    case 512: return KF<512>::lds(rows_lds, kg);
+    default: return KF<1024>::lds(rows_lds, kg);
+  }
+}
 
 int table_cols(int n) {
   switch (n) {
@@ -1742,18 +2079,66 @@ RunPlan plan_runs(hh_ctx* c, const double* hp, int64_t g) {
   // i1 - i0 = ((COLS - 1) apix + 2 rpx apix + 2 slack) / rise; one more row for float32 rounding
   const double span = ((double)(table_cols(c->n) - 1) + 2.0 * c->geom.rpx) * c->geom.apix + 2.0 * c->geom.slack;
   const double need = (std::floor(span / (double)(float)rise_all) + 4.0) * c->geom.n_units;
-  if (need > 64.0) return plan;  // KT<N>::ROWS_MAX: one lane per staged row
-  plan.rows_lds = (int)need;
+  plan.rows_lds = need <= 64.0 ? (int)need : 0;  // KT<N>::ROWS_MAX: one lane per staged row
   plan.rows = (2 * imax_all + 1) * c->geom.n_units;
   if ((size_t)plan.rows * (c->n / 2) * sizeof(float2) > HH_TABLE_BYTES_MAX) return plan;
+  // fused pass: subunit indices i with lo <= i rise <= hi for four columns, hi - lo = (3 + 2 rpx) apix + 2 slack
+  if (c->fused_path) {
+    const double span4 = (3.0 + 2.0 * c->geom.rpx) * c->geom.apix + 2.0 * c->geom.slack;
+    const double kg = (std::floor(span4 / (double)(float)rise_all) + 2.0) * c->geom.n_units;
+    int rows_f = std::max(plan.rows, (int)std::min(kg, 1.0e6));
+    rows_f += (4 - rows_f % 8 + 8) % 8;  // = 4 (mod 8): the eight ky rows of the slice start in different banks
+    if (kg <= 16.0 && fused_lds(c->n, rows_f, (int)kg) <= 160 * 1024 - 1024) {
+      plan.fused = true;
+      plan.kg = (int)kg;
+      plan.rows_f = rows_f;
+    }
+  }
+  if (!plan.fused && plan.rows_lds == 0) return plan;
   plan.len = len;
   plan.ok = true;
   return plan;
 }
 
 // Second pass + scores of one batch whose intermediate is in c->d_inter.
-int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinArgs& pending) {
+// Scores of one batch whose moments (and, with several segments, q) the second pass has left.
+// Second pass + scores of one batch whose intermediate is in c->d_inter.
+// Scores of one batch whose moments (and, with several segments, q) the second pass has left.
+int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinArgs& pending,
+                const double* partials = nullptr) {
   const int npart = npart_for(c->n);
+  if (!partials) partials = c->d_partials;
+  if (c->n_segments == 1) {
+    float* const out = d_scores + g0;
+    if (g0 + nb < g) {
+      pending = FinArgs{partials, out, nb, npart, c->ref[0]};
+    } else {
+      ProfScope ps(c, 2);
+      const int threads = c->n < 64 ? c->n : 256;  // teams of min(64, n) lanes, one candidate each
+      hipLaunchKernelGGL(k_finalize, dim3(std::min(1024, (nb + 3) / 4)), dim3(threads), 0, c->stream, partials,
+                         npart, (int64_t)nb, c->ref[0], out);
+    }
+    HH_HIP(c, hipGetLastError());
+  } else {
+    // several segments: one MFMA contraction of the batch's q against all segments' centred
+    // spectra, then Pearson per (segment, candidate)
+    const int rows = c->n / 2 + 1;
+    const size_t K = (size_t)rows * c->n;
+    ProfScope ps(c, 2);
+    hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
+                       c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
+    const int total = nb * c->n_segments;
+    hipLaunchKernelGGL(k_sum_partials, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, c->stream, partials, npart,
+                       nb, c->d_psum);
+    hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_psum, 1,
+                       c->d_cpart, rows, c->b_pad, c->s_pad, nb, c->n_segments, c->d_ref, d_scores, g, g0);
+    HH_HIP(c, hipGetLastError());
+  }
+  return HH_OK;
+}
+
+// Second pass + scores of one batch whose intermediate is in c->d_inter.
+int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinArgs& pending) {
   SecondArgs sa{};
   sa.inter = c->d_inter;
   sa.twtab = c->d_tw;
@@ -1765,36 +2150,56 @@ int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores,
   int rc;
   if (c->n_segments == 1) {
     rc = dispatch_second<EPI_SCORE>(c, sa, nb);
-    if (rc) return rc;
-    float* const out = d_scores + g0;
-    if (g0 + nb < g) {
-      pending = FinArgs{c->d_partials, out, nb, npart, c->ref[0]};
-    } else {
-      ProfScope ps(c, 2);
-      const int threads = c->n < 64 ? c->n : 256;  // teams of min(64, n) lanes, one candidate each
-      hipLaunchKernelGGL(k_finalize, dim3(std::min(1024, (nb + 3) / 4)), dim3(threads), 0, c->stream, c->d_partials,
-                         npart, (int64_t)nb, c->ref[0], out);
-    }
-    HH_HIP(c, hipGetLastError());
   } else {
-    // several segments: q of the batch -> HBM, one MFMA contraction against all segments' centred
-    // spectra, then Pearson per (segment, candidate)
-    sa.q_out = c->d_q;
+    sa.q_out = c->d_q;  // several segments: q of the batch -> HBM for the contraction
     rc = dispatch_second<EPI_QSTORE>(c, sa, nb);
-    if (rc) return rc;
-    const int rows = c->n / 2 + 1;
-    const size_t K = (size_t)rows * c->n;
-    ProfScope ps(c, 2);
-    hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
-                       c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
-    const int total = nb * c->n_segments;
-    hipLaunchKernelGGL(k_sum_partials, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, c->stream, c->d_partials, npart,
-                       nb, c->d_psum);
-    hipLaunchKernelGGL(k_finalize_segments, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->d_psum, 1,
-                       c->d_cpart, rows, c->b_pad, c->s_pad, nb, c->n_segments, c->d_ref, d_scores, g, g0);
-    HH_HIP(c, hipGetLastError());
   }
+  if (rc) return rc;
+  return scores_tail(c, g, g0, nb, d_scores, pending);
+}
+
+template <int N>
+int launch_factors(hh_ctx* c, const FactorArgs& a, int batch) {
+  ProfScope ps(c, 0);  // reported in the first-pass slot: it is what is left of the first pass
+  FactorArgs args = a;
+  args.count = batch;
+  hipLaunchKernelGGL((k_column_factors<N>), dim3(batch), dim3(N), 0, c->stream, args);
+  HH_HIP(c, hipGetLastError());
   return HH_OK;
+}
+
+template <int N, int EPI, int LOG>
+int launch_fused(hh_ctx* c, const FusedArgs& a, int layers) {
+  using K = KF<N>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_pass<N, EPI, LOG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  ProfScope ps(c, 1);
+  hipLaunchKernelGGL((k_fused_pass<N, EPI, LOG>), dim3(a.n_kb, a.factor_layers + layers + (a.fin.n > 0 ? 1 : 0)),
+                     dim3(K::THREADS), K::lds(a.rows_lds, a.kg), c->stream, a);
+  HH_HIP(c, hipGetLastError());
+  return HH_OK;
+}
+
+int dispatch_factors(hh_ctx* c, const FactorArgs& a, int batch) {
+#define HH_CALL(NN) launch_factors<NN>(c, a, batch)
+  HH_SWITCH_N(c, HH_CALL);
+#undef HH_CALL
+}
+
+template <int EPI, int LOG>
+int dispatch_fused_n(hh_ctx* c, const FusedArgs& a, int layers) {
+#define HH_CALL(NN) launch_fused<NN, EPI, LOG>(c, a, layers)
+  HH_SWITCH_N(c, HH_CALL);
+#undef HH_CALL
+}
+
+int dispatch_fused(hh_ctx* c, const FusedArgs& a, int layers) {
+  if (c->n_segments == 1) return c->log_flag ? dispatch_fused_n<EPI_SCORE, 1>(c, a, layers) : dispatch_fused_n<EPI_SCORE, 0>(c, a, layers);
+  return c->log_flag ? dispatch_fused_n<EPI_QSTORE, 1>(c, a, layers) : dispatch_fused_n<EPI_QSTORE, 0>(c, a, layers);
 }
 
 // The sweep with the shared-twist first pass (plan.ok): batches are whole runs (or pieces of one
@@ -1815,6 +2220,17 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
     HH_HIP(c, hipMalloc(&c->d_table, need));
     c->cap_table = need;
   }
+  if (plan.fused) {
+    const size_t need_eg = (size_t)2 * c->max_batch * plan.kg * c->n * sizeof(float);  // two halves, alternating
+    if (need_eg > c->cap_eg) {
+      if (c->d_eg) HH_HIP(c, hipFree(c->d_eg));
+      c->d_eg = nullptr;
+      c->cap_eg = 0;
+      HH_HIP(c, hipMalloc(&c->d_eg, need_eg));
+      c->cap_eg = need_eg;
+    }
+    if (!c->d_cgs) HH_HIP(c, hipMalloc(&c->d_cgs, (size_t)2 * c->max_batch * (c->n / 4) * sizeof(int)));
+  }
   if (runs > c->cap_runs) {
     if (c->d_run_imax) HH_HIP(c, hipFree(c->d_run_imax));
     c->d_run_imax = nullptr;
@@ -1824,6 +2240,43 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   }
   HH_HIP(c, hipMemcpyAsync(c->d_run_imax, c->h_run_imax.data(), (size_t)runs * sizeof(int), hipMemcpyHostToDevice,
                            c->stream));
+  // the batches of the sweep: whole runs (or pieces of one run), in order
+  struct Batch {
+    int64_t g0;      // first candidate
+    int nb;          // candidates
+    int64_t r0;      // first run
+    int run_len;     // candidates per run inside the batch (a piece of one run counts as one run)
+    int64_t q0;      // first run of the table group the batch belongs to
+  };
+  std::vector<Batch> batches;
+  for (int64_t q0 = 0; q0 < runs; q0 += per_group) {
+    const int nq = (int)std::min<int64_t>(per_group, runs - q0);
+    for (int64_t r0 = q0; r0 < q0 + nq; r0 += per_batch) {
+      const int nr = (int)std::min<int64_t>(per_batch, q0 + nq - r0);
+      const int64_t first = r0 * plan.len, count = (int64_t)nr * plan.len;
+      for (int64_t g0 = first; g0 < first + count; g0 += c->max_batch) {
+        const int nb = (int)std::min<int64_t>(c->max_batch, first + count - g0);
+        batches.push_back(Batch{g0, nb, r0, (int)std::min<int64_t>(plan.len, nb), q0});
+      }
+    }
+  }
+  const size_t eg_half = (size_t)c->max_batch * plan.kg * c->n;
+  const size_t cg_half = (size_t)c->max_batch * (c->n / 4);
+  auto factor_args = [&](const Batch& bt, int half) {
+    FactorArgs fa{};
+    fa.params = d_params + 4 * bt.g0;
+    fa.units = c->d_units;
+    fa.run_imax = c->d_run_imax + bt.r0;
+    fa.eg = c->d_eg + half * eg_half;
+    fa.cgs = c->d_cgs + half * cg_half;
+    fa.run_len = bt.run_len;
+    fa.kg = plan.kg;
+    fa.rows_lds = plan.rows_f;
+    fa.count = bt.nb;
+    fa.g = c->geom;
+    return fa;
+  };
+
   TableArgs ta{};
   ta.units = c->d_units;
   ta.twtab = c->d_tw;
@@ -1833,41 +2286,77 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   ta.rows_lds = plan.rows_lds;
   ta.g = c->geom;
   FinArgs pending{};
-  int64_t batch_no = 0;
-  for (int64_t q0 = 0; q0 < runs; q0 += per_group) {
-    const int nq = (int)std::min<int64_t>(per_group, runs - q0);
-    {
+  int64_t table_group = -1;
+  for (size_t bi = 0; bi < batches.size(); ++bi) {
+    const Batch& bt = batches[bi];
+    if (bt.q0 != table_group) {  // this group's tables, one launch
+      table_group = bt.q0;
+      const int nq = (int)std::min<int64_t>(per_group, runs - bt.q0);
       c->prof_now = c->profiling > 0;
-      ta.params = d_params + 4 * q0 * plan.len;
+      ta.params = d_params + 4 * bt.q0 * plan.len;
       ta.table = c->d_table;
-      ta.run_imax = c->d_run_imax + q0;
+      ta.run_imax = c->d_run_imax + bt.q0;
       ta.run_len = (int)std::min<int64_t>(plan.len, 1 << 30);
       ta.fin = FinArgs{};
       int rows = 0;
-      for (int r = 0; r < nq; ++r) rows = std::max(rows, (2 * c->h_run_imax[(size_t)(q0 + r)] + 1) * c->geom.n_units);
+      for (int r = 0; r < nq; ++r) rows = std::max(rows, (2 * c->h_run_imax[(size_t)(bt.q0 + r)] + 1) * c->geom.n_units);
       const int rc = dispatch_run_table(c, ta, nq, rows);
       if (rc) return rc;
     }
-    for (int64_t r0 = q0; r0 < q0 + nq; r0 += per_batch) {
-      const int nr = (int)std::min<int64_t>(per_batch, q0 + nq - r0);
-      ta.table = c->d_table + (size_t)(r0 - q0) * plan.rows * nky;
-      ta.run_imax = c->d_run_imax + r0;
-      ta.run_len = plan.len <= c->max_batch ? (int)plan.len : c->max_batch + 1;
-      // pieces of the run(s): one piece when a batch holds whole runs
-      const int64_t first = r0 * plan.len, count = (int64_t)nr * plan.len;
-      for (int64_t g0 = first; g0 < first + count; g0 += c->max_batch, ++batch_no) {
-        const int nb = (int)std::min<int64_t>(c->max_batch, first + count - g0);
-        c->prof_now = c->profiling > 0 && (batch_no % c->profiling) == 0;
-        if (c->prof_now) c->prof_candidates += nb;
-        ta.params = d_params + 4 * g0;
-        ta.fin = pending;
-        int rc = dispatch_first_table(c, ta, nb);
-        if (rc) return rc;
-        pending = FinArgs{};
-        rc = second_and_scores(c, g, g0, nb, d_scores, pending);
+    c->prof_now = c->profiling > 0 && ((int64_t)bi % c->profiling) == 0;
+    if (c->prof_now) c->prof_candidates += bt.nb;
+    ta.table = c->d_table + (size_t)(bt.r0 - bt.q0) * plan.rows * nky;
+    ta.run_imax = c->d_run_imax + bt.r0;
+    ta.run_len = plan.len <= c->max_batch ? (int)plan.len : c->max_batch + 1;
+    ta.params = d_params + 4 * bt.g0;
+    int rc;
+    if (plan.fused) {
+      // build + transform + moments without an intermediate.  The batch's column factors were
+      // computed by leading layers of the previous batch's launch (its own launch for the first).
+      const int half = (int)(bi & 1);
+      if (bi == 0) {
+        rc = dispatch_factors(c, factor_args(bt, half), bt.nb);
         if (rc) return rc;
       }
+      FusedArgs fu{};
+      fu.params = ta.params;
+      fu.twtab = c->d_tw;
+      fu.table = ta.table;
+      fu.run_imax = ta.run_imax;
+      fu.eg = c->d_eg + half * eg_half;
+      fu.cgs = c->d_cgs + half * cg_half;
+      fu.w2 = c->d_w2;
+      double* const part = c->d_partials + (size_t)half * c->max_batch * npart_for(c->n) * 3;
+      fu.partials = part;
+      fu.q_out = c->n_segments > 1 ? c->d_q : nullptr;
+      fu.kb_list = c->d_kb_list;
+      fu.n_kb = c->n_kb;
+      fu.batch = bt.nb;
+      fu.run_len = bt.run_len;
+      fu.groups_per_run = (fu.run_len + HH_KF_CPW - 1) / HH_KF_CPW;
+      fu.cap = plan.rows;
+      fu.rows_lds = plan.rows_f;
+      fu.kg = plan.kg;
+      fu.n_units = c->geom.n_units;
+      fu.fin = pending;
+      if (bi + 1 < batches.size()) {
+        fu.next = factor_args(batches[bi + 1], half ^ 1);
+        fu.factor_layers = (fu.next.count + c->n_kb - 1) / c->n_kb;
+      }
+      const int runs_here = (bt.nb + fu.run_len - 1) / fu.run_len;
+      rc = dispatch_fused(c, fu, runs_here * fu.groups_per_run);
+      if (rc) return rc;
+      pending = FinArgs{};
+      rc = scores_tail(c, g, bt.g0, bt.nb, d_scores, pending, part);
+      if (rc) return rc;
+      continue;
     }
+    ta.fin = pending;
+    rc = dispatch_first_table(c, ta, bt.nb);
+    if (rc) return rc;
+    pending = FinArgs{};
+    rc = second_and_scores(c, g, bt.g0, bt.nb, d_scores, pending);
+    if (rc) return rc;
   }
   c->prof_now = false;
   return HH_OK;
@@ -1875,7 +2364,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
 
 int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const double* h_params = nullptr) {
   const RunPlan plan = plan_runs(c, h_params, g);
-  c->last_first_pass = plan.ok ? 1 : 0;
+  c->last_first_pass = plan.ok ? (plan.fused ? 2 : 1) : 0;
   if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan);
   FinArgs pending{};
   int64_t batch_no = 0;
@@ -2028,8 +2517,8 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   c->stream = c->own_stream;
   HH_CREATE_HIP(hipMalloc(&c->d_tw, (size_t)n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
-  HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)max_batch * npart_for(n) * 3 * sizeof(double)));
-  HH_CREATE_HIP(hipMemset(c->d_partials, 0, (size_t)max_batch * npart_for(n) * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
+  HH_CREATE_HIP(hipMemset(c->d_partials, 0, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMalloc(&c->d_psum, (size_t)max_batch * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
 
@@ -2066,6 +2555,8 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_ref);
   (void)hipFree(c->d_kb_list);
   (void)hipFree(c->d_table);
+  (void)hipFree(c->d_eg);
+  (void)hipFree(c->d_cgs);
   (void)hipFree(c->d_run_imax);
 
   (void)hipFree(c->d_spec);
@@ -2254,7 +2745,7 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   HH_HIP(c, hipMalloc(&c->d_kb_list, kb_list.size() * sizeof(int)));
   HH_HIP(c, hipMemcpyAsync(c->d_kb_list, kb_list.data(), kb_list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   // rows of skipped ky blocks keep zero moments
-  HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)c->max_batch * npart_for(n) * 3 * sizeof(double), c->stream));
+  HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)2 * c->max_batch * npart_for(n) * 3 * sizeof(double), c->stream));
   c->n_kb = (int)kb_list.size();
   c->kb_mask = kb_mask;
   c->s_pad = s_pad;
@@ -2288,6 +2779,7 @@ int hh_last_first_pass(const hh_ctx* c) { return c ? c->last_first_pass : HH_ERR
 int hh_set_table_path(hh_ctx* c, int on) {
   if (!c) return HH_ERR_ARG;
   c->table_path = on ? 1 : 0;
+  c->fused_path = on == 1 ? 0 : 1;  // 1: run tables through the two-pass pipeline; 2 (default): fused where it fits
   return HH_OK;
 }
 

@@ -171,15 +171,19 @@ class SweepEngine:
                 self._check(self._L.hh_sweep_device_mirrored(self._ctx, C.c_void_p(d_params), _ptr(hp, C.c_double),
                                                              int(n_candidates), C.c_void_p(d_scores)))
 
-    def set_table_path(self, on: bool):
-        """Allow (default) or forbid the shared-twist first pass; scores agree to float32 rounding."""
+    def set_table_path(self, mode=2):
+        """How runs of candidates that share (twist, csym, rot) are swept: 0 / False = like any other
+        list (raster + two transforms per candidate), 1 = run tables + second pass, 2 / True = the
+        fused pass where it fits (default).  Scores agree to float32 rounding."""
+        mode = 2 if mode is True else int(mode)
         with self._lock:
-            self._check(self._L.hh_set_table_path(self._ctx, int(bool(on))))
+            self._check(self._L.hh_set_table_path(self._ctx, mode))
 
     @property
     def last_first_pass(self) -> str:
-        """First pass of the last sweep: "transform" (per candidate) or "run_tables" (shared twist)."""
-        return "run_tables" if self._L.hh_last_first_pass(self._ctx) == 1 else "transform"
+        """Pipeline of the last sweep: "transform" (raster + column transform per candidate),
+        "run_tables" (shared-twist tables + second pass) or "fused" (shared-twist, no intermediate)."""
+        return {1: "run_tables", 2: "fused"}.get(self._L.hh_last_first_pass(self._ctx), "transform")
 
     def synchronize(self):
         with self._lock:

@@ -482,14 +482,21 @@ def test_masks_that_skip_ky_blocks(kind):
 
 # ---------------------------------------------------------------------------- shared-twist first pass
 def _both_first_passes(eng, params):
-    """Scores of the same list through the run-table first pass and through the per-candidate transform."""
-    eng.set_table_path(True)
+    """Scores of the same list through the shared-twist pipelines (fused; run tables + second pass) and through
+    the per-candidate transform; the two shared-twist results must agree with each other as well."""
+    eng.set_table_path(2)
     tab = eng.sweep(params)
     used = eng.last_first_pass
-    eng.set_table_path(False)
+    eng.set_table_path(1)
+    two = eng.sweep(params)
+    if used == "fused":
+        assert eng.last_first_pass in ("run_tables", "transform")
+        if eng.last_first_pass == "run_tables":
+            np.testing.assert_allclose(tab, two, rtol=0, atol=2e-5)
+    eng.set_table_path(0)
     gen = eng.sweep(params)
     assert eng.last_first_pass == "transform"
-    eng.set_table_path(True)
+    eng.set_table_path(2)
     return tab, gen, used
 
 
@@ -518,7 +525,7 @@ def test_run_table_first_pass_matches_transform_and_oracle(n, apix, max_batch, c
         eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, **geo)
         eng.set_reference(img, mask)
         tab, gen, used = _both_first_passes(eng, grid.params)
-    assert used == "run_tables"
+    assert used == "fused"
     np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
     pick = np.arange(0, len(grid), 7 if n < 256 else 23)
     ref = O.sweep_cpu(img, grid.params[pick, :3], mask, apix=apix, helical_diameter=d, ball_radius=br, rot=rot, **geo)
@@ -541,13 +548,13 @@ def test_run_table_first_pass_units_segments_masks_and_fallbacks():
             eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, units=units, dy=1.5 * k)
             eng.set_reference(img, mask, log=bool(k))
             tab, gen, used = _both_first_passes(eng, grid.params)
-            assert used == "run_tables"
+            assert used == "fused"
             np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
         # several segments: the contraction path behind the same first pass
         eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
         eng.set_reference(np.stack([img, img[::-1].copy(), img[:, ::-1].copy()]), masks[0])
         tab, gen, used = _both_first_passes(eng, grid.params)
-        assert used == "run_tables" and tab.shape == (3, len(grid))
+        assert used == "fused" and tab.shape == (3, len(grid))
         np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
         ref = O.sweep_cpu(img[::-1].copy(), grid.params[::9, :3], masks[0], apix=apix, helical_diameter=d, ball_radius=br)
         np.testing.assert_allclose(tab[1, ::9], ref, rtol=0, atol=SCORE_TOL)
@@ -594,7 +601,7 @@ def test_run_table_first_pass_device_api_full_sizes():
             a = torch.empty((1, len(grid)), dtype=torch.float32, device="cuda")
             b = torch.empty_like(a)
             eng.sweep_device(dp.data_ptr(), len(grid), a.data_ptr(), host_params=grid.params)
-            assert eng.last_first_pass == "run_tables"
+            assert eng.last_first_pass == "fused"
             eng.sweep_device(dp.data_ptr(), len(grid), b.data_ptr())
             assert eng.last_first_pass == "transform"
             eng.synchronize()
