@@ -214,7 +214,7 @@ def main():
         if host_api is not None:
             out["host_api_value"] = host_api  # hh_sweep with host buffers, PCIe-inclusive
         if prof is not None and prof["n_second_pass"] > 0:
-            out["roofline"] = roofline(prof, n, b_alg)
+            out["roofline"] = roofline(prof, n, b_alg, eng.last_first_pass)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
@@ -223,18 +223,33 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(prof, n, b_alg):
-    """The two-pass pipeline against the HBM roofline, as SURVEY.md section 8d defines it:
-    achieved = B_alg(N) bytes per candidate x candidates / device time of the launches that process
-    them (first pass + second pass + the rare stand-alone finalize), all measured with HIP events
-    on the sweep's stream over sampled batches of the timed region.  B_alg = 4 N^2 + 16 N (N/2+1)
-    spans both kernels, so neither is priced against it alone; `kernels` gives each kernel's own
-    share (the half spectrum it writes / reads, 8 N (N/2+1) B per candidate) and its average launch
-    duration for comparison with rocprofv3.  `traffic` = measured bytes per batch (both kernels)
-    from the calibrated FETCH_SIZE / WRITE_SIZE passes in profiles/traffic.json."""
+F32_VECTOR_PEAK = 157.3e12  # FLOP/s, MI355X fp32 vector (= fp32 MFMA) peak, MI355X_MICROARCH.md
+
+PIPELINES = {
+    # pipeline -> ((JSON name, traffic.json key, what it moves per candidate), ...) for profile slots 0 and 1
+    "transform": (("k_first_pass", "first_pass", "writes the half spectrum"),
+                  ("k_second_pass", "second_pass", "reads the half spectrum")),
+    "run_tables": (("k_first_pass_table", "first_pass_table", "writes the half spectrum"),
+                   ("k_second_pass", "second_pass", "reads the half spectrum")),
+    "fused": (("k_column_factors", "column_factors", "first batch of a sweep only; later batches ride in k_fused_pass"),
+              ("k_fused_pass", "fused_pass", "no intermediate: table slice + column factors from L2, moments out")),
+}
+
+
+def roofline(prof, n, b_alg, pipeline):
+    """achieved = B_alg(N) bytes per candidate x candidates / device time of the
+    launches that process them, all measured with HIP events on the sweep's stream over sampled
+    batches of the timed region, against the 8 TB/s HBM peak.  B_alg = 4 N^2 + 16 N (N/2+1) prices a
+    pipeline that writes the column-transformed half spectrum to HBM and reads it back.  The
+    `transform` and `run_tables` pipelines do exactly that (`kernels` gives each kernel's own half
+    and its measured traffic).  The `fused` pipeline keeps the intermediate in LDS, so it moves
+    almost none of B_alg (`traffic` << `achieved` x time) and the same formula can exceed 1.0: the
+    section-8d roofline does not bound it.  What bounds it is vector issue; `valu` prices the
+    section-8d FLOP count (5 N^2 log2 N per candidate) against the fp32 vector peak.
+    `traffic` = measured bytes per batch from the calibrated FETCH_SIZE / WRITE_SIZE passes in
+    profiles/traffic.json."""
     half = 8 * n * (n // 2 + 1)
-    per = {"first_pass": (prof["ms_first_pass"], prof["n_first_pass"], half, "written"),
-           "second_pass": (prof["ms_second_pass"], prof["n_second_pass"], half, "read")}
+    slots = (("ms_first_pass", "n_first_pass"), ("ms_second_pass", "n_second_pass"))
     cand = prof["candidates"]
     tfile = ROOT / "profiles" / "traffic.json"  # written from the rocprofv3 --pmc passes (see DESIGN.md)
     measured = {}
@@ -244,31 +259,47 @@ def roofline(prof, n, b_alg):
         except Exception:
             measured = {}
     kernels = {}
-    for name, (ms, launches, bytes_per_cand, what) in per.items():
-        if launches == 0:  # the fused pass has no separate first pass
+    main_launches = max(prof["n_first_pass"], prof["n_second_pass"])
+    for (name, tkey, what), (ms_key, n_key) in zip(PIPELINES[pipeline], slots):
+        launches = prof[n_key]
+        if launches == 0:
             continue
-        per_launch = cand / launches
-        avg_us = 1e3 * ms / launches
-        gbps = bytes_per_cand * per_launch / (avg_us * 1e-6) / 1e9
-        kernels["k_" + name] = {"launches": launches, "avg_us": avg_us, "candidates_per_launch": per_launch,
-                                "alg_bytes_per_candidate": bytes_per_cand, "moves": what, "GBps": gbps,
-                                "frac": gbps / (HBM_PEAK / 1e9), "traffic": measured.get(name)}
+        avg_us = 1e3 * prof[ms_key] / launches
+        entry = {"launches": launches, "avg_us": avg_us, "role": what, "traffic": measured.get(tkey)}
+        if pipeline != "fused":
+            per_launch = cand / launches
+            gbps = half * per_launch / (avg_us * 1e-6) / 1e9
+            entry.update({"candidates_per_launch": per_launch, "alg_bytes_per_candidate": half, "GBps": gbps,
+                          "frac": gbps / (HBM_PEAK / 1e9)})
+        elif name == "k_fused_pass":
+            entry["candidates_per_launch"] = cand / launches
+        kernels[name] = entry
     # run-table builds (one launch per sweep) are timed on every sweep but serve all of its batches:
     # scale them to the sampled share of the candidates
     share = cand / max(1, prof.get("candidates_total", cand))
     device_ms = prof["ms_first_pass"] + prof["ms_second_pass"] + prof["ms_finalize"] + prof["ms_centres"] * share
     achieved = b_alg * cand / (device_ms * 1e-3) / 1e9
     traffic = None
-    if all(v["traffic"] is not None for v in kernels.values()):
-        traffic = sum(v["traffic"] for v in kernels.values())
-    return {
-        "bound": "hbm", "kernel": "k_first_pass + k_second_pass (two-pass pipeline, per batch)",
+    dominant = [v for k, v in kernels.items() if k != "k_column_factors"]
+    if dominant and all(v["traffic"] is not None for v in dominant):
+        traffic = sum(v["traffic"] for v in dominant)
+    out = {
+        "bound": "hbm", "pipeline": pipeline,
+        "kernel": " + ".join(k for k in kernels if k != "k_column_factors") + " (per batch)",
         "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9),
         "traffic": traffic, "alg_bytes_per_candidate": b_alg,
-        "candidates_per_launch": cand / max(prof["n_first_pass"], prof["n_second_pass"]), "device_ms_sampled": device_ms,
+        "candidates_per_launch": cand / main_launches, "device_ms_sampled": device_ms,
         "run_table_ms_per_sweep": (prof["ms_centres"] / prof["n_centres"]) if prof["n_centres"] else None,
         "kernels": kernels,
     }
+    if pipeline == "fused":
+        flops = 5.0 * n * n * np.log2(n)  # r2c 2-D FFT, 11.8 MFLOP at 512
+        tf = flops * cand / (device_ms * 1e-3) / 1e12
+        out["note"] = ("fused pass: the half spectrum never goes to HBM, so B_alg is not moved and frac can exceed 1; "
+                       "the kernel is vector-issue bound (see valu)")
+        out["valu"] = {"bound": "fp32 vector", "alg_flop_per_candidate": flops, "achieved": tf,
+                       "peak": F32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf / (F32_VECTOR_PEAK / 1e12)}
+    return out
 
 
 if __name__ == "__main__":

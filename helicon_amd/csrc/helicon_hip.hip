@@ -60,8 +60,14 @@
 #ifndef HH_KF_CPW
 #define HH_KF_CPW 16       // fused pass: candidates per workgroup
 #endif
+#ifndef HH_FUSED_BATCH
+#define HH_FUSED_BATCH 4096  // fused pass: candidates per launch (whole runs)
+#endif
 #ifndef HH_KF_WPS
 #define HH_KF_WPS 4        // fused pass: waves per SIMD the register allocator must leave room for
+#endif
+#ifndef HH_FFT_SWZ
+#define HH_FFT_SWZ 1       // xor-swizzled slots for the first exchange of every transform (bank conflicts)
 #endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
@@ -215,16 +221,16 @@ __device__ __forceinline__ void fill_twiddles_lds(float2* lds, int t, const floa
   if constexpr (P::n > 3) fill_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::lds3>(lds, t, table);
 }
 
-// The exchange buffers are NOT padded: measured on MI355X, neither kernel is sensitive to the
-// LDS bank conflicts of the stride-8 / stride-64 scatters (identical time with and without an extra
-// slot every 8), and the unpadded buffers are what lets four K_A workgroups share a CU.
+// The exchange buffers are NOT padded (the unpadded buffers are what lets four K_A workgroups, or two
+// fused workgroups, share a CU); the first exchange's stride-8 scatter is xor-swizzled instead.
 // One Stockham stage.  Lane t owns butterflies j = t + q*T (q < 8/R); butterfly j reads
 // in[j + r*N/R] — always the lane's own register slots v[q + r*(8/R)] — and writes
 // out[(j/NS)*NS*R + (j mod NS) + r*NS].  The last stage's outputs land back in the same slots,
 // so on return v[m] = X[t + m*T].
-template <int N, int R, int NS, bool LAST, int OFF, int LOFF, typename TW>
+template <int N, int R, int NS, bool LAST, int OFF, int LOFF, bool SWZ1, typename TW>
 __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   constexpr int T = N / 8, NB = 8 / R, E = imin(NS, T);
+  constexpr bool SWZ = SWZ1 && NS == 1 && R == 8 && !LAST && N >= 128;
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     float2 a[R];
@@ -238,6 +244,15 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
     if constexpr (LAST) {
 #pragma unroll
       for (int r = 0; r < R; ++r) v[q + r * NB] = a[r];
+    } else if constexpr (SWZ) {
+      // first stage (NS = 1, R = 8): lane j's eight outputs go to slots 8 j + (r ^ s), s = (j >> 1) & 7.
+      // Plain slots 8 j + r put 16 lanes of a ds_write_b64 group on two bank pairs (8-way conflict);
+      // with the xor the 16 lanes hit 16 different pairs.  Byte address = (64 j | 8 s) ^ 8 r.
+      const int j = t + q * T;
+      const unsigned bs = (unsigned)(j * 64) | (unsigned)(((j >> 1) & 7) << 3);
+      char* const base = reinterpret_cast<char*>(buf);
+#pragma unroll
+      for (int r = 0; r < R; ++r) *reinterpret_cast<float2*>(base + (bs ^ (unsigned)(r << 3))) = a[r];
     } else {
       const int j = t + q * T;
       const int k = j & (NS - 1);
@@ -248,28 +263,49 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
   }
   if constexpr (!LAST) {
     group_sync<T>();
+    if constexpr (SWZ) {
+      // element n = t + m T sits in slot (n & ~7) | ((n & 7) ^ ((n >> 4) & 7))
+      if constexpr (T == 64) {  // (n >> 4) & 7 = (t >> 4) ^ 4 (m & 1): two bases, immediate offsets
+        const int e0 = (t & ~7) | ((t & 7) ^ (t >> 4)), e1 = e0 ^ 4;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
+        for (int m = 0; m < 8; ++m) v[m] = buf[((m & 1) ? e1 : e0) + m * T];
+      } else if constexpr (T == 128) {  // (n >> 4) & 7 = (t >> 4) & 7 for every m
+        const int e0 = (t & ~7) | ((t & 7) ^ ((t >> 4) & 7));
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[e0 + m * T];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int nn = t + m * T;
+          v[m] = buf[(nn & ~7) | ((nn & 7) ^ ((nn >> 4) & 7))];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
+    }
     group_sync<T>();
   }
 }
 
 // In: v[m] = x[t + m*T].  Out: v[m] = X[t + m*T], X = forward DFT (exp(-2 pi i nk/N)).
 // All T lanes of the transform must call it (group_sync inside; block-wide for T > 64).
-template <int N, typename TW>
+// SWZ1: xor-swizzle the first exchange (worth it where LDS, not vector issue, is the tighter resource:
+// the second pass and the fused pass; the raster + column-transform kernel is vector-issue bound).
+template <int N, bool SWZ1 = false, typename TW>
 __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   using P = Plan<N>;
   using W = TwN<N>;
-  fft_stage<N, P::r0, 1, false, 0, 0>(v, tw, t, buf);
+  fft_stage<N, P::r0, 1, false, 0, 0, SWZ1>(v, tw, t, buf);
   if constexpr (P::n == 2) {
-    fft_stage<N, P::r1, P::r0, true, W::off1, W::lds1>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, true, W::off1, W::lds1, false>(v, tw, t, buf);
   } else if constexpr (P::n == 3) {
-    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1>(v, tw, t, buf);
-    fft_stage<N, P::r2, P::r0 * P::r1, true, W::off2, W::lds2>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, false>(v, tw, t, buf);
+    fft_stage<N, P::r2, P::r0 * P::r1, true, W::off2, W::lds2, false>(v, tw, t, buf);
   } else {
-    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1>(v, tw, t, buf);
-    fft_stage<N, P::r2, P::r0 * P::r1, false, W::off2, W::lds2>(v, tw, t, buf);
-    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, W::off3, W::lds3>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, false>(v, tw, t, buf);
+    fft_stage<N, P::r2, P::r0 * P::r1, false, W::off2, W::lds2, false>(v, tw, t, buf);
+    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, W::off3, W::lds3, false>(v, tw, t, buf);
   }
 }
 
@@ -1111,7 +1147,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
       ld2 = src[2 * K::THREADS];
       ld3 = src[3 * K::THREADS];
     }
-    if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
+    if (!(HH_ABLATE & 16)) fft_lanes<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]
 
     if (kb == 0 && (gi == 0 || T > 64)) {
       // Row 0 of H packs two real sequences: C = DFT(F1[0,:]) + i DFT(F1[N/2,:]); un-pack it into the
@@ -1430,7 +1466,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       if (tid + 3 * K::THREADS < n_e4) dst[tid + 3 * K::THREADS] = nx3;
       if (tid < N / 4) cgs[(cur ^ 1) * (N / 4) + tid] = ncg;
     }
-    if (!(HH_ABLATE & 16)) fft_lanes<N>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
+    if (!(HH_ABLATE & 16)) fft_lanes<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
 
     bool scored = false;
     if (kb == 0 && (gi == 0 || T > 64)) {
@@ -1787,7 +1823,8 @@ struct hh_ctx {
   int fused_path = 1;            // 0: shared-twist runs go through the two-pass pipeline (k_first_pass_table + k_second_pass)
   float* d_eg = nullptr;         // fused pass: [max_batch][kg][N] column factors
   int* d_cgs = nullptr;          // fused pass: [max_batch][N/4]
-  size_t cap_eg = 0;
+  size_t cap_eg = 0, cap_cgs = 0;
+  int cap_partials = 0;          // candidates per half of d_partials
   int last_first_pass = 0;       // what the last sweep ran: 0 per-candidate transform, 1 run tables
   unsigned long long kb_mask = ~0ull;
   int s_pad = 0, b_pad = 0;
@@ -2204,10 +2241,27 @@ int dispatch_fused(hh_ctx* c, const FusedArgs& a, int layers) {
 
 // The sweep with the shared-twist first pass (plan.ok): batches are whole runs (or pieces of one
 // run); the tables of as many runs as fit HH_TABLE_BYTES_MAX are built by one launch ahead of them.
+// d_partials holds two halves of `batch` candidates each (zero-filled: rows of ky blocks the mask skips
+// are never written)
+int ensure_partials(hh_ctx* c, int batch) {
+  if (batch <= c->cap_partials) return HH_OK;
+  if (c->d_partials) HH_HIP(c, hipFree(c->d_partials));
+  c->d_partials = nullptr;
+  c->cap_partials = 0;
+  const size_t bytes = (size_t)2 * batch * npart_for(c->n) * 3 * sizeof(double);
+  HH_HIP(c, hipMalloc(&c->d_partials, bytes));
+  HH_HIP(c, hipMemsetAsync(c->d_partials, 0, bytes, c->stream));
+  c->cap_partials = batch;
+  return HH_OK;
+}
+
 int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const RunPlan& plan) {
   const int64_t runs = g / plan.len;
   const int nky = c->n / 2;
-  const int64_t per_batch = plan.len <= c->max_batch ? c->max_batch / plan.len : 1;
+  // The fused pass has no intermediate to hold, so its batches are not tied to max_batch: long
+  // launches even out the tail of the grid (C2: 3.2 M candidates/s at 250 per launch, 3.8 M at 4000).
+  const int bmax = plan.fused && c->n_segments == 1 ? std::max(c->max_batch, HH_FUSED_BATCH) : c->max_batch;
+  const int64_t per_batch = plan.len <= bmax ? bmax / plan.len : 1;
   const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
   int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
   per_group = std::min<int64_t>(std::min<int64_t>(per_group, runs), 65535);
@@ -2221,7 +2275,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
     c->cap_table = need;
   }
   if (plan.fused) {
-    const size_t need_eg = (size_t)2 * c->max_batch * plan.kg * c->n * sizeof(float);  // two halves, alternating
+    const size_t need_eg = (size_t)2 * bmax * plan.kg * c->n * sizeof(float);  // two halves, alternating
     if (need_eg > c->cap_eg) {
       if (c->d_eg) HH_HIP(c, hipFree(c->d_eg));
       c->d_eg = nullptr;
@@ -2229,7 +2283,15 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       HH_HIP(c, hipMalloc(&c->d_eg, need_eg));
       c->cap_eg = need_eg;
     }
-    if (!c->d_cgs) HH_HIP(c, hipMalloc(&c->d_cgs, (size_t)2 * c->max_batch * (c->n / 4) * sizeof(int)));
+    if ((size_t)bmax > c->cap_cgs) {
+      if (c->d_cgs) HH_HIP(c, hipFree(c->d_cgs));
+      c->d_cgs = nullptr;
+      c->cap_cgs = 0;
+      HH_HIP(c, hipMalloc(&c->d_cgs, (size_t)2 * bmax * (c->n / 4) * sizeof(int)));
+      c->cap_cgs = (size_t)bmax;
+    }
+    const int rc = ensure_partials(c, bmax);
+    if (rc) return rc;
   }
   if (runs > c->cap_runs) {
     if (c->d_run_imax) HH_HIP(c, hipFree(c->d_run_imax));
@@ -2254,14 +2316,14 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
     for (int64_t r0 = q0; r0 < q0 + nq; r0 += per_batch) {
       const int nr = (int)std::min<int64_t>(per_batch, q0 + nq - r0);
       const int64_t first = r0 * plan.len, count = (int64_t)nr * plan.len;
-      for (int64_t g0 = first; g0 < first + count; g0 += c->max_batch) {
-        const int nb = (int)std::min<int64_t>(c->max_batch, first + count - g0);
+      for (int64_t g0 = first; g0 < first + count; g0 += bmax) {
+        const int nb = (int)std::min<int64_t>(bmax, first + count - g0);
         batches.push_back(Batch{g0, nb, r0, (int)std::min<int64_t>(plan.len, nb), q0});
       }
     }
   }
-  const size_t eg_half = (size_t)c->max_batch * plan.kg * c->n;
-  const size_t cg_half = (size_t)c->max_batch * (c->n / 4);
+  const size_t eg_half = (size_t)bmax * plan.kg * c->n;
+  const size_t cg_half = (size_t)bmax * (c->n / 4);
   auto factor_args = [&](const Batch& bt, int half) {
     FactorArgs fa{};
     fa.params = d_params + 4 * bt.g0;
@@ -2307,7 +2369,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
     if (c->prof_now) c->prof_candidates += bt.nb;
     ta.table = c->d_table + (size_t)(bt.r0 - bt.q0) * plan.rows * nky;
     ta.run_imax = c->d_run_imax + bt.r0;
-    ta.run_len = plan.len <= c->max_batch ? (int)plan.len : c->max_batch + 1;
+    ta.run_len = plan.len <= bmax ? (int)plan.len : bmax + 1;
     ta.params = d_params + 4 * bt.g0;
     int rc;
     if (plan.fused) {
@@ -2326,7 +2388,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       fu.eg = c->d_eg + half * eg_half;
       fu.cgs = c->d_cgs + half * cg_half;
       fu.w2 = c->d_w2;
-      double* const part = c->d_partials + (size_t)half * c->max_batch * npart_for(c->n) * 3;
+      double* const part = c->d_partials + (size_t)half * bmax * npart_for(c->n) * 3;
       fu.partials = part;
       fu.q_out = c->n_segments > 1 ? c->d_q : nullptr;
       fu.kb_list = c->d_kb_list;
@@ -2519,6 +2581,7 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMemset(c->d_partials, 0, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
+  c->cap_partials = max_batch;
   HH_CREATE_HIP(hipMalloc(&c->d_psum, (size_t)max_batch * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
 
@@ -2745,7 +2808,7 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   HH_HIP(c, hipMalloc(&c->d_kb_list, kb_list.size() * sizeof(int)));
   HH_HIP(c, hipMemcpyAsync(c->d_kb_list, kb_list.data(), kb_list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   // rows of skipped ky blocks keep zero moments
-  HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)2 * c->max_batch * npart_for(n) * 3 * sizeof(double), c->stream));
+  HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)2 * c->cap_partials * npart_for(n) * 3 * sizeof(double), c->stream));
   c->n_kb = (int)kb_list.size();
   c->kb_mask = kb_mask;
   c->s_pad = s_pad;

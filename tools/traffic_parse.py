@@ -48,9 +48,14 @@ def main(fetch_dir, write_dir, n=512, batch=256, out=None):
                            "calib_read_WRITE_SIZE": pick(write, "k_calib_read")[0],
                            "calib_write_FETCH_SIZE": pick(fetch, "k_calib_write")[0]}}
     kernels = {}
-    for name, frag in (("first_pass", f"k_first_pass<{n}, 0>"), ("second_pass", f"k_second_pass<{n}, 0, 1>")):
-        fv, fl = pick(fetch, frag)
-        wv, wl = pick(write, frag)
+    for name, frag in (("first_pass", f"k_first_pass<{n}, 0>"), ("second_pass", f"k_second_pass<{n}, 0, 1>"),
+                       ("first_pass_table", f"k_first_pass_table<{n}>"), ("fused_pass", f"k_fused_pass<{n}, 0, 1>"),
+                       ("column_factors", f"k_column_factors<{n}>"), ("run_table", f"k_run_table<{n}>")):
+        try:
+            fv, fl = pick(fetch, frag)
+            wv, wl = pick(write, frag)
+        except KeyError:
+            continue
         kernels[name] = {"launches": fl, "FETCH_SIZE": fv, "WRITE_SIZE": wv,
                          "read_bytes_per_launch": fv * f_unit, "write_bytes_per_launch": wv * w_unit,
                          "bytes_per_launch": fv * f_unit + wv * w_unit}

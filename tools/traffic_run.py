@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Workload for the rocprofv3 --pmc traffic passes: calibration launches (known byte counts in the
-sweep's own access shapes) followed by one C2 sweep.  Run it once per counter:
+sweep's own access shapes) followed by one C2 sweep through each of the three pipelines.  Run it once per counter:
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out_fetch -- python tools/traffic_run.py
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out_write -- python tools/traffic_run.py
@@ -27,5 +27,7 @@ clean = eng.simulate(1.2, 4.75, 1)
 img = (clean + np.random.default_rng(0).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
 eng.set_reference(img)
 grid = H.build_grid(H.sweep_axis(0.01, 4.00, 0.01), H.sweep_axis(4.000, 5.245, 0.005), (1,), tube_length=n * apix)
-scores = eng.sweep(grid.params)
-print("best", grid.params[int(np.argmax(scores[0]))], "batch", eng.max_batch)
+for mode in (2, 1, 0):  # fused; run tables + second pass; raster + two transforms per candidate
+    eng.set_table_path(mode)
+    scores = eng.sweep(grid.params)
+    print(eng.last_first_pass, "best", grid.params[int(np.argmax(scores[0]))], "batch", eng.max_batch)

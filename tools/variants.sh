@@ -10,6 +10,6 @@ for line in sys.stdin:
     line=line.strip()
     if not line.startswith('{'): continue
     d=json.loads(line); k=d['roofline']['kernels']
-    print('$lib', '$extra', 'cand/s=%.0f' % d['value'], 'KA=%.1fus' % k['k_first_pass']['avg_us'], 'KB=%.1fus' % k['k_second_pass']['avg_us'], 'batch', d['config']['batch'], 'truth', d['argmax']['is_truth'])
+    print('$lib', '$extra', 'cand/s=%.0f' % d['value'], ' '.join('%s=%.1fus' % (n, v['avg_us']) for n, v in k.items()), 'batch', d['config']['batch'], d['config']['first_pass'], 'truth', d['argmax']['is_truth'])
 " || exit 1
 done
