@@ -816,9 +816,15 @@ struct KT {
 };
 
 // One table per run: row (i, u) = sum over the csym copies s of G_(i,s,u), for i in [-imax, imax].
+// A workgroup takes SUB table rows; the float64 trigonometry of their csym copies' row coordinates
+// is done once (one lane per copy, through LDS), then thread ky sums the footprint's rows.
 template <int N>
 __global__ __launch_bounds__(256) void k_run_table(TableArgs a) {
   using K = KT<N>;
+  constexpr int PAIRS = 256;  // (table row, csym copy) pairs resolved per round
+  __shared__ float yc_s[PAIRS];
+  __shared__ float2 tw_s[N];  // the phase table, gathered at (ky y) mod N: LDS latency instead of L2's
+  for (int i = threadIdx.x; i < N; i += 256) tw_s[i] = a.twtab[i];
   const int run = blockIdx.y;
   const DevGeom& g = a.g;
   Cand c = decode_candidate(a.params + 4 * (size_t)run * a.run_len, g);
@@ -827,27 +833,62 @@ __global__ __launch_bounds__(256) void k_run_table(TableArgs a) {
   float2* const tab = a.table + (size_t)run * a.cap * K::NKY;
   const float rp = (float)g.rpx;
   const float k2 = g.inv_sigma2 * 1.44269504088896341f;
-  for (int row = blockIdx.x * K::SUB; row < min(rows, (int)(blockIdx.x + 1) * K::SUB); ++row) {
-    const int ir = row / g.n_units, u = row % g.n_units;
-    for (int ky = threadIdx.x; ky < K::NKY; ky += 256) {
-      float2 acc = make_float2(0.f, 0.f);
-      float alt = 0.f;  // ky = N/2: sum ey (-1)^y
-      for (int s = 0; s < c.csym; ++s) {
-        const float yc = centre_position(c, g, a.units, (ir * c.csym + s) * g.n_units + u).x;
+  const int row0 = blockIdx.x * K::SUB;
+  const int nrow = min(K::SUB, rows - row0);
+  if (nrow <= 0) return;
+  float2 acc[K::SUB][(K::NKY + 255) / 256];
+  float alt[K::SUB];  // ky = N/2: sum ey (-1)^y (thread 0 only needs it)
+#pragma unroll
+  for (int r = 0; r < K::SUB; ++r) {
+    alt[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < (K::NKY + 255) / 256; ++q) acc[r][q] = make_float2(0.f, 0.f);
+  }
+  const int total = nrow * c.csym;  // pairs, ordered (row, s)
+  for (int p0 = 0; p0 < total; p0 += PAIRS) {
+    const int np = min(PAIRS, total - p0);
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+      const int p = p0 + threadIdx.x;
+      const int row = row0 + p / c.csym, sc = p % c.csym;
+      const int ir = row / g.n_units, u = row % g.n_units;
+      yc_s[threadIdx.x] = centre_position(c, g, a.units, (ir * c.csym + sc) * g.n_units + u).x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < K::SUB; ++r) {
+      // pairs of local row r inside this round: [r csym, (r + 1) csym) intersected with [p0, p0 + np)
+      const int lo = max(r * c.csym, p0), hi = min((r + 1) * c.csym, p0 + np);
+      for (int p = lo; p < hi; ++p) {
+        const float yc = yc_s[p - p0];
         const float cy = yc * g.inv_apix + (float)(N / 2);
         if (!(cy >= -rp - 1.f && cy <= (float)N + rp)) continue;
         const int y0 = max(0, (int)ceilf(cy - rp)), y1 = min(N - 1, (int)floorf(cy + rp));
         for (int y = y0; y <= y1; ++y) {
           const float dyv = (float)(y - N / 2) * g.apix - yc;
           const float e = __builtin_amdgcn_exp2f(-dyv * dyv * k2);
-          const float2 w = a.twtab[(ky * y) & (N - 1)];
-          acc.x = fmaf(e, w.x, acc.x);
-          acc.y = fmaf(e, w.y, acc.y);
-          alt += (y & 1) ? -e : e;
+          alt[r] += (y & 1) ? -e : e;
+#pragma unroll
+          for (int q = 0; q < (K::NKY + 255) / 256; ++q) {
+            const int ky = threadIdx.x + 256 * q;
+            const float2 w = tw_s[(ky * y) & (N - 1)];
+            acc[r][q].x = fmaf(e, w.x, acc[r][q].x);
+            acc[r][q].y = fmaf(e, w.y, acc[r][q].y);
+          }
         }
       }
-      if (ky == 0) acc.y = alt;
-      tab[(size_t)row * K::NKY + ky] = acc;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < K::SUB; ++r) {
+    if (r >= nrow) break;
+#pragma unroll
+    for (int q = 0; q < (K::NKY + 255) / 256; ++q) {
+      const int ky = threadIdx.x + 256 * q;
+      if (ky >= K::NKY) continue;
+      float2 o = acc[r][q];
+      if (ky == 0) o.y = alt[r];
+      tab[(size_t)(row0 + r) * K::NKY + ky] = o;
     }
   }
 }

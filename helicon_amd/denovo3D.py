@@ -396,8 +396,10 @@ def sweep(images, twists, rises, csyms=(1,), *, apix, helical_diameter, ball_rad
     eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
                      tilt=tilt, psi=psi, dy=dy)
     eng.set_reference(imgs, mask, log=log)
+    from .distributed import harmless_rise
+
     params = grid.params.copy()
-    params[~grid.valid, 1] = 1.0  # skipped pairs still occupy a slot; give them a harmless rise
+    params[~grid.valid, 1] = harmless_rise(grid)  # skipped pairs still occupy a slot
     return finish_sweep(eng.sweep(params), grid)
 
 

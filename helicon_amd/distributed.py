@@ -13,11 +13,19 @@ import numpy as np
 
 from .grid import CandidateGrid, shard_bounds
 
-__all__ = ["gather_scores", "sweep_distributed", "shard_params"]
+__all__ = ["gather_scores", "sweep_distributed", "shard_params", "harmless_rise"]
 
 
-def shard_params(params: np.ndarray, rank: int, world: int):
-    lo, hi, per = shard_bounds(len(params), rank, world)
+def harmless_rise(grid: CandidateGrid) -> float:
+    """Rise given to the pairs the reference's driver skips (they still occupy a slot; their scores
+    are discarded): the smallest valid rise, so the slot changes neither the list's run structure
+    nor the lattice size the library plans for."""
+    ok = grid.params[grid.valid, 1]
+    return float(ok.min()) if len(ok) else 1.0
+
+
+def shard_params(params: np.ndarray, rank: int, world: int, align: int = 1):
+    lo, hi, per = shard_bounds(len(params), rank, world, align)
     return params[lo:hi], lo, hi, per
 
 
@@ -44,13 +52,13 @@ def sweep_distributed(engine, grid: CandidateGrid, group=None):
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     params = grid.params.copy()
-    params[~grid.valid, 1] = 1.0
-    mine, lo, hi, per = shard_params(params, rank, world)
+    params[~grid.valid, 1] = harmless_rise(grid)
+    mine, lo, hi, per = shard_params(params, rank, world, align=len(grid.rises))
     dev = torch.device("cuda", engine.device)
     d_params = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
     d_scores = torch.empty((engine.n_segments, max(hi - lo, 1)), dtype=torch.float32, device=dev)
     engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     if hi > lo:
-        engine.sweep_device(d_params.data_ptr(), hi - lo, d_scores.data_ptr())
+        engine.sweep_device(d_params.data_ptr(), hi - lo, d_scores.data_ptr(), host_params=mine)
     full = gather_scores(d_scores[:, : hi - lo], len(params), per, group)
     return full.cpu().numpy()

@@ -107,10 +107,14 @@ def layer_line_mask(ny, nx, r_lo=2.0, r_hi=None, axial_bins=None, half_width=1) 
     return m & sel[None, :]
 
 
-def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int, int]:
+def shard_bounds(n_items: int, rank: int, world: int, align: int = 1) -> tuple[int, int, int]:
     """Contiguous block partition of the flat candidate index:
-    rank k owns [k*ceil(G/W), min(G, (k+1)*ceil(G/W))).  Returns (lo, hi, per_rank)."""
+    rank k owns [k*per, min(G, (k+1)*per)), per = ceil(G/W) rounded up to a multiple of ``align``
+    (the number of rises: shards then start on a twist, which keeps every shard a list of whole
+    shared-twist runs for the library's fused pass).  Returns (lo, hi, per_rank)."""
     per = -(-n_items // world)
+    if align > 1:
+        per = -(-per // align) * align
     lo = min(n_items, rank * per)
     hi = min(n_items, lo + per)
     return lo, hi, per

@@ -56,6 +56,14 @@ def test_shard_bounds_cover_exactly_once():
             seen[lo:hi] += 1
         assert (seen == 1).all()
         assert per * w >= n
+    # run-aligned shards (what sweep_distributed uses): every shard starts on a twist, still an exact cover
+    for n, w, align in ((100000, 8, 250), (100000, 3, 250), (600000, 7, 250), (4000, 8, 100), (90, 4, 30)):
+        seen = np.zeros(n, dtype=int)
+        for r in range(w):
+            lo, hi, per = H.shard_bounds(n, r, w, align)
+            assert lo % align == 0 and per % align == 0 and 0 <= lo <= hi <= n
+            seen[lo:hi] += 1
+        assert (seen == 1).all()
 
 
 def test_header_symbols_all_exported_and_bound():
