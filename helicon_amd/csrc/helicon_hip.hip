@@ -1070,21 +1070,26 @@ __device__ __forceinline__ float amp_to_q(float2 f) {
   return a;
 }
 
-// Sum over the TL = min(T, 64) lanes of a transform group inside one wavefront; every lane of the
-// group's first 16-lane row (in particular its lane 0) ends up with the total.  A full wavefront
-// uses DPP within the 16-lane rows and four scalar lane reads across them: no LDS traffic.
+// Sum over the TL = min(T, 64) lanes of a transform group inside one wavefront.  A full wavefront
+// uses DPP only (quad permutes and mirrors inside the 16-lane rows, then row_bcast15 / row_bcast31
+// across them): no LDS traffic, the total lands in lane 63.  Sub-wavefront groups shuffle and leave
+// the total in the group's lane 0.  group_sum_lane<TL>() names that lane.
+template <int TL>
+__device__ __forceinline__ constexpr int group_sum_lane() { return TL == 64 ? 63 : 0; }
+
 template <int TL>
 __device__ __forceinline__ float group_sum(float v) {
   if constexpr (TL == 64) {
-#define HH_DPP_ADD(CTRL) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true))
-    HH_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
-    HH_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
-    HH_DPP_ADD(0x141);  // row_half_mirror
-    HH_DPP_ADD(0x140);  // row_mirror: every lane of a row holds the row's sum
+#define HH_DPP_ADD(CTRL, ROWS) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false))
+    HH_DPP_ADD(0xB1, 0xF);   // quad_perm [1,0,3,2]
+    HH_DPP_ADD(0x4E, 0xF);   // quad_perm [2,3,0,1]
+    HH_DPP_ADD(0x141, 0xF);  // row_half_mirror
+    HH_DPP_ADD(0x140, 0xF);  // row_mirror: every lane of a row holds the row's sum
+    HH_DPP_ADD(0x142, 0xA);  // row_bcast15 into rows 1 and 3: R0+R1, R2+R3
+    HH_DPP_ADD(0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 = R0+R1+R2+R3
 #undef HH_DPP_ADD
-    const int iv = __float_as_int(v);
-    return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
-           (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+    return v;
   } else {
 #pragma unroll
     for (int off = TL / 2; off > 0; off >>= 1) v += __shfl_down(v, off, TL);
@@ -1166,7 +1171,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
   auto slot = [&](int i) { const int q = i * K::THREADS + tid; return (q & 7) * K::PROW + 2 * (q >> 3); };
   // one partial triple per (row, wavefront of the row); lane 0 of the group's wavefront writes it
   const int wave_in_row = T > 64 ? (t >> 6) : 0;
-  const bool writer = (t & (TL - 1)) == 0;
+  const bool writer = (t & (TL - 1)) == group_sum_lane<TL>();
 
 #pragma unroll 1
   for (int cc = 0; cc < nc; ++cc) {
@@ -1450,7 +1455,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   __syncthreads();
 
   const int wave_in_row = T > 64 ? (t >> 6) : 0;
-  const bool writer = (t & (TL - 1)) == 0;
+  const bool writer = (t & (TL - 1)) == group_sum_lane<TL>();
 
 #pragma unroll 1
   for (int cc = 0; cc < nc; ++cc) {
@@ -2103,7 +2108,7 @@ struct RunPlan {
   int rows_f = 0;      // fused: table rows staged per ky
 };
 
-constexpr int64_t HH_MIN_RUN = 32;             // shorter runs do not amortise their table
+constexpr int64_t HH_MIN_RUN = 8;              // shorter runs do not amortise their table and workgroup granularity
 constexpr size_t HH_TABLE_BYTES_MAX = 1ull << 30;
 
 size_t fused_lds(int n, int rows_lds, int kg) {
@@ -2880,10 +2885,10 @@ int hh_sweep_device_mirrored(hh_ctx* c, const double* d_params, const double* h_
 
 int hh_last_first_pass(const hh_ctx* c) { return c ? c->last_first_pass : HH_ERR_ARG; }
 
-int hh_set_table_path(hh_ctx* c, int on) {
+int hh_set_table_path(hh_ctx* c, int mode) {
   if (!c) return HH_ERR_ARG;
-  c->table_path = on ? 1 : 0;
-  c->fused_path = on == 1 ? 0 : 1;  // 1: run tables through the two-pass pipeline; 2 (default): fused where it fits
+  c->table_path = mode ? 1 : 0;
+  c->fused_path = mode == 1 ? 0 : 1;  // 1: run tables through the two-pass pipeline; 2 (default): fused where it fits
   return HH_OK;
 }
 

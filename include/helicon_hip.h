@@ -117,17 +117,20 @@ int hh_sweep_device(hh_ctx* ctx, const double* d_params, int64_t n_candidates, f
 
 /* hh_sweep_device for a caller that also holds the candidate list on the host (h_params, same
  * G x 4 values; may be NULL).  The library reads h_params during the call only, to see how the
- * list is ordered: when it consists of equal-length runs (>= 32) of candidates that share
- * (twist, csym, rot) — the twist-major grid of app.py:2319-2403 — and tilt = psi = 0, the first
- * pass tabulates each run's column transforms once and no candidate is rastered or
- * column-transformed individually.  Scores agree with hh_sweep_device to
- * float32 rounding.  hh_sweep does the same analysis on its host list.  hh_set_table_path(ctx, 0)
- * switches this path off (1, the default, on). */
+ * list is ordered: when it consists of equal-length runs (>= 8) of candidates that share
+ * (twist, csym, rot) — the twist-major grid of app.py:2319-2403 — and tilt = psi = 0, each run's
+ * column transforms are tabulated once and no candidate is rastered or column-transformed
+ * individually; where the table slice and the candidate's column factors fit in LDS the whole
+ * candidate is built, row-transformed and reduced inside the compute unit (the "fused" pipeline,
+ * DESIGN.md section 4), otherwise the table feeds the two-pass pipeline.  Scores agree with
+ * hh_sweep_device to float32 rounding.  hh_sweep does the same analysis on its host list.
+ * hh_set_table_path(ctx, mode): 0 = never, 1 = run tables + second pass only, 2 = fused where it
+ * fits (default). */
 int hh_sweep_device_mirrored(hh_ctx* ctx, const double* d_params, const double* h_params, int64_t n_candidates,
                              float* d_scores);
-int hh_set_table_path(hh_ctx* ctx, int on);
-/* Which first pass the last sweep of this context ran: 0 = per-candidate raster + column
- * transform, 1 = run tables. */
+int hh_set_table_path(hh_ctx* ctx, int mode);
+/* Which pipeline the last sweep of this context ran: 0 = per-candidate raster + column transform +
+ * second pass, 1 = run tables + second pass, 2 = fused. */
 int hh_last_first_pass(const hh_ctx* ctx);
 
 /* arg-max with ties resolved to the lowest index (np.argmax); NaN never wins. */

@@ -561,7 +561,7 @@ def test_run_table_first_pass_units_segments_masks_and_fallbacks():
 
         # lists the plan must refuse: ragged runs, a run that is too short, a bad rise, tilt/psi
         eng.set_reference(img, masks[0])
-        for bad in (grid.params[:-5], grid.params[:20], np.vstack([grid.params[:36], grid.params[40:76]])):
+        for bad in (grid.params[:-5], grid.params[:5], np.vstack([grid.params[:36], grid.params[40:76]])):
             eng.sweep(bad)
             assert eng.last_first_pass == "transform"
         holes = grid.params.copy()

@@ -30,7 +30,8 @@ def run(name, eng, grid, reps=2):
     dt = (time.perf_counter() - t0) / reps
     best = [tuple(np.round(grid.params[int(np.argmax(s)), :3], 4)) for s in sc[:3]]
     print(f"{name}: {len(grid)} candidates x {sc.shape[0]} segment(s) in {dt * 1e3:.1f} ms = "
-          f"{len(grid) / dt:,.0f} cand/s ({len(grid) * sc.shape[0] / dt:,.0f} scores/s); best {best}", flush=True)
+          f"{len(grid) / dt:,.0f} cand/s ({len(grid) * sc.shape[0] / dt:,.0f} scores/s); pipeline {eng.last_first_pass}; "
+          f"best {best}", flush=True)
 
 
 tw, rs = H.sweep_axis(0.01, 4.00, 0.01), H.sweep_axis(4.000, 5.245, 0.005)
