@@ -1,20 +1,27 @@
 // helicon_hip.hip — MI355X (gfx950 / CDNA4) kernels + C ABI for the denovo3D (twist, rise, Csym)
 // sweep.  See include/helicon_hip.h for the boundary and DESIGN.md for the data layout.
 //
-// Per candidate (reference semantics in brackets):
-//   K_A  k_first_pass   rasterise the helical lattice of Gaussian balls straight into the FFT input
-//                       registers [utils.py:91-106, 153-172], FFT every image COLUMN (along y) with
-//                       two real columns packed into one complex transform, write the half spectrum
-//                       H (N/2 x N complex, row 0 packs ky=0 and ky=N/2) in 128-byte lines of
-//                       8 ky x 1 column pair.
-//   K_B  k_second_pass  transpose 8-row blocks of H through LDS, FFT every row along x ->
-//                       F[ky][kx] on the half plane, then a=|F|, q=log1p(a) [transforms.py:805-810]
-//                       and the three masked moments sum w q, sum w q^2, sum w (E-Ebar) q with
-//                       Hermitian weights w in {0,1,2}, wave-shuffle + LDS reduced.
-//   K_C  finalize       Pearson coefficient from the moments [analysis.py:793-799] (an extra
-//                       workgroup layer of the next K_A launch, or k_finalize).
-//   several segments:   K_B keeps q, k_segment_corr contracts it with all segments' centred
-//                       spectra on the f32 matrix cores, k_finalize_segments scores S x G.
+// Three pipelines give the same scores; reference semantics in brackets:
+//   any candidate list ("transform"):
+//     k_first_pass    rasterise the helical lattice of Gaussian balls straight into the FFT input
+//                     registers [utils.py:91-106, 153-172], FFT every image COLUMN (along y) with
+//                     two real columns packed into one complex transform, write the half spectrum
+//                     H (N/2 x N complex, row 0 packs ky=0 and ky=N/2) in 128-byte lines of
+//                     8 ky x 1 column pair.
+//     k_second_pass   transpose 8-row blocks of H through LDS, FFT every row along x ->
+//                     F[ky][kx] on the half plane, then a=|F|, q=log1p(a) [transforms.py:805-810]
+//                     and the three masked moments sum w q, sum w q^2, sum w (E-Ebar) q with
+//                     Hermitian weights w in {0,1,2}; one partial triple per spectrum row.
+//   runs of candidates sharing (twist, csym, rot), no tilt/psi — the driver's twist-major grid:
+//     k_run_table     column transforms of every subunit's footprint, once per run.
+//     k_first_pass_table + k_second_pass ("run tables"): H as a short weighted sum of table rows.
+//     k_fused_pass ("fused", the default): one ky block of up to 16 candidates per workgroup, H built
+//                     in LDS from the table slice and the candidate's column factors, row FFT and
+//                     moments in place; no intermediate in HBM.
+//   finalize          Pearson coefficient from the moments [analysis.py:793-799]: grid layer 0 of the
+//                     next batch's first kernel, or k_finalize.
+//   several segments: the second / fused pass keeps q, k_segment_corr contracts it with all segments'
+//                     centred spectra on the f32 matrix cores, k_finalize_segments scores S x G.
 // Everything is wave64 code: an N-point FFT is owned by N/8 lanes holding 8 points each
 // (one wavefront for N = 512), Stockham radix-8/4/2 stages exchange through LDS.
 #include <hip/hip_runtime.h>
