@@ -2194,13 +2194,13 @@ RunPlan plan_runs(hh_ctx* c, const double* hp, int64_t g) {
 // Scores of one batch whose moments (and, with several segments, q) the second pass has left.
 // Second pass + scores of one batch whose intermediate is in c->d_inter.
 // Scores of one batch whose moments (and, with several segments, q) the second pass has left.
-int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinArgs& pending,
+int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, bool last, float* d_scores, FinArgs& pending,
                 const double* partials = nullptr) {
   const int npart = npart_for(c->n);
   if (!partials) partials = c->d_partials;
   if (c->n_segments == 1) {
     float* const out = d_scores + g0;
-    if (g0 + nb < g) {
+    if (!last) {  // the next launch of this range scores the batch in its grid layer 0
       pending = FinArgs{partials, out, nb, npart, c->ref[0]};
     } else {
       ProfScope ps(c, 2);
@@ -2228,7 +2228,7 @@ int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinAr
 }
 
 // Second pass + scores of one batch whose intermediate is in c->d_inter.
-int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores, FinArgs& pending) {
+int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, bool last, float* d_scores, FinArgs& pending) {
   SecondArgs sa{};
   sa.inter = c->d_inter;
   sa.twtab = c->d_tw;
@@ -2245,7 +2245,7 @@ int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, float* d_scores,
     rc = dispatch_second<EPI_QSTORE>(c, sa, nb);
   }
   if (rc) return rc;
-  return scores_tail(c, g, g0, nb, d_scores, pending);
+  return scores_tail(c, g, g0, nb, last, d_scores, pending);
 }
 
 template <int N>
@@ -2308,8 +2308,11 @@ int ensure_partials(hh_ctx* c, int batch) {
   return HH_OK;
 }
 
-int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const RunPlan& plan) {
-  const int64_t runs = g / plan.len;
+// Candidates [first, first + count) of the list of g (count = whole runs of plan.len).
+int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const RunPlan& plan, int64_t first_cand,
+               int64_t count_cand) {
+  d_params += 4 * first_cand;  // indices below are relative to the range; scores and g0 get first_cand back
+  const int64_t runs = count_cand / plan.len;
   const int nky = c->n / 2;
   // The fused pass has no intermediate to hold, so its batches are not tied to max_batch: long
   // launches even out the tail of the grid (C2: 3.2 M candidates/s at 250 per launch, 3.8 M at 4000).
@@ -2462,7 +2465,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       rc = dispatch_fused(c, fu, runs_here * fu.groups_per_run);
       if (rc) return rc;
       pending = FinArgs{};
-      rc = scores_tail(c, g, bt.g0, bt.nb, d_scores, pending, part);
+      rc = scores_tail(c, g, first_cand + bt.g0, bt.nb, bi + 1 == batches.size(), d_scores, pending, part);
       if (rc) return rc;
       continue;
     }
@@ -2470,21 +2473,19 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
     rc = dispatch_first_table(c, ta, bt.nb);
     if (rc) return rc;
     pending = FinArgs{};
-    rc = second_and_scores(c, g, bt.g0, bt.nb, d_scores, pending);
+    rc = second_and_scores(c, g, first_cand + bt.g0, bt.nb, bi + 1 == batches.size(), d_scores, pending);
     if (rc) return rc;
   }
   c->prof_now = false;
   return HH_OK;
 }
 
-int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const double* h_params = nullptr) {
-  const RunPlan plan = plan_runs(c, h_params, g);
-  c->last_first_pass = plan.ok ? (plan.fused ? 2 : 1) : 0;
-  if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan);
+// Candidates [first, first + count) through the general pipeline (raster + two transforms each).
+int sweep_transform(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, int64_t first, int64_t count) {
   FinArgs pending{};
   int64_t batch_no = 0;
-  for (int64_t g0 = 0; g0 < g; g0 += c->max_batch, ++batch_no) {
-    const int nb = (int)std::min<int64_t>(c->max_batch, g - g0);
+  for (int64_t g0 = first; g0 < first + count; g0 += c->max_batch, ++batch_no) {
+    const int nb = (int)std::min<int64_t>(c->max_batch, first + count - g0);
     c->prof_now = c->profiling > 0 && (batch_no % c->profiling) == 0;
     if (c->prof_now) c->prof_candidates += nb;
     FirstArgs fa{};
@@ -2498,11 +2499,54 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
     int rc = dispatch_first<MODE_RASTER>(c, fa, nb);
     if (rc) return rc;
     pending = FinArgs{};
-    rc = second_and_scores(c, g, g0, nb, d_scores, pending);
+    rc = second_and_scores(c, g, g0, nb, g0 + nb == first + count, d_scores, pending);
     if (rc) return rc;
   }
   c->prof_now = false;
   return HH_OK;
+}
+
+int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const double* h_params = nullptr) {
+  RunPlan plan = plan_runs(c, h_params, g);
+  c->last_first_pass = plan.ok ? (plan.fused ? 2 : 1) : 0;
+  if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan, 0, g);
+  // A list that starts inside a run (a shard cut anywhere) or ends with a partial run: the whole runs in
+  // the middle still take the shared-twist pipeline, the two ragged ends the general one.
+  if (h_params && c->table_path && !c->geom.has_rot && g >= 2 * HH_MIN_RUN) {
+    auto same = [&](int64_t i, int64_t j) {
+      return h_params[4 * i] == h_params[4 * j] && h_params[4 * i + 2] == h_params[4 * j + 2] &&
+             h_params[4 * i + 3] == h_params[4 * j + 3];
+    };
+    int64_t head = 1;
+    while (head < g && same(head, 0)) ++head;
+    int64_t len = 1;
+    while (head + len < g && same(head + len, head)) ++len;
+    const int64_t count = head < g ? (g - head) / len * len : 0;
+    if (head < g && head < len && len >= HH_MIN_RUN && count >= len) {
+      plan = plan_runs(c, h_params + 4 * head, count);
+      if (plan.ok) {
+        c->last_first_pass = plan.fused ? 2 : 1;
+        int rc = sweep_transform(c, d_params, g, d_scores, 0, head);
+        if (rc) return rc;
+        rc = sweep_runs(c, d_params, g, d_scores, plan, head, count);
+        if (rc) return rc;
+        return head + count < g ? sweep_transform(c, d_params, g, d_scores, head + count, g - head - count) : HH_OK;
+      }
+    }
+    // aligned start, partial last run
+    len = head;
+    const int64_t whole = g / len * len;
+    if (len >= HH_MIN_RUN && whole >= len && whole < g) {
+      plan = plan_runs(c, h_params, whole);
+      if (plan.ok) {
+        c->last_first_pass = plan.fused ? 2 : 1;
+        const int rc = sweep_runs(c, d_params, g, d_scores, plan, 0, whole);
+        if (rc) return rc;
+        return sweep_transform(c, d_params, g, d_scores, whole, g - whole);
+      }
+    }
+  }
+  return sweep_transform(c, d_params, g, d_scores, 0, g);
 }
 
 int check_ready(hh_ctx* c, bool need_ref) {

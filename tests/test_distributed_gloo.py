@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_total, n_seg, q):
+def _worker(rank, world, port, n_total, n_seg, aligned, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,7 +26,9 @@ def _worker(rank, world, port, n_total, n_seg, q):
         grid = build_grid(np.arange(1.0, 1.0 + 0.1 * 13, 0.1)[:13], np.arange(4.0, 4.0 + 0.5 * (n_total // 13 + 1), 0.5)[: n_total // 13 + 1],
                           (1,), tube_length=1e9)
         params = grid.params[:n_total]
-        mine, lo, hi, per = shard_params(params, rank, world)
+        # aligned: shards start on a twist (what sweep_distributed does), else the plain ceil(G/W) blocks
+        mine, lo, hi, per = shard_params(params, rank, world, align=len(grid.rises) if aligned else 1)
+        assert not aligned or lo % len(grid.rises) == 0
         # stand-in scores: a deterministic function of the candidate, so the gather can be checked
         base = torch.from_numpy((mine[:, 0] * 1000 + mine[:, 1]).astype(np.float32))
         local = torch.stack([base + 0.25 * s for s in range(n_seg)]) if hi > lo else torch.empty((n_seg, 0))
@@ -43,13 +45,13 @@ def _worker(rank, world, port, n_total, n_seg, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,n_seg", [(101, 1), (64, 3), (1, 1)])
-def test_allgather_of_scores_world2(n_total, n_seg):
+@pytest.mark.parametrize("n_total,n_seg,aligned", [(101, 1, False), (64, 3, False), (1, 1, False), (101, 2, True)])
+def test_allgather_of_scores_world2(n_total, n_seg, aligned):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, n_seg, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, n_seg, aligned, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=90) for _ in range(world)]

@@ -559,11 +559,16 @@ def test_run_table_first_pass_units_segments_masks_and_fallbacks():
         ref = O.sweep_cpu(img[::-1].copy(), grid.params[::9, :3], masks[0], apix=apix, helical_diameter=d, ball_radius=br)
         np.testing.assert_allclose(tab[1, ::9], ref, rtol=0, atol=SCORE_TOL)
 
-        # lists the plan must refuse: ragged runs, a run that is too short, a bad rise, tilt/psi
+        # ragged lists: the whole runs in the middle keep the shared-twist pipeline, the ends go through the
+        # general one; a list with no whole run, or too short, is swept by the general pipeline alone
         eng.set_reference(img, masks[0])
-        for bad in (grid.params[:-5], grid.params[:5], np.vstack([grid.params[:36], grid.params[40:76]])):
-            eng.sweep(bad)
-            assert eng.last_first_pass == "transform"
+        full = eng.sweep(grid.params)[0]
+        idx = np.arange(len(grid))
+        for sel, want in ((idx[:-5], "fused"), (idx[7:], "fused"), (idx[30:-11], "fused"), (idx[:5], "transform"),
+                          (np.r_[idx[:36], idx[40:76]], "transform"), (idx[3:33], "fused")):
+            got = eng.sweep(grid.params[sel])[0]
+            assert eng.last_first_pass == want, (sel[0], sel[-1], eng.last_first_pass)
+            np.testing.assert_allclose(got, full[sel], rtol=0, atol=2e-5)
         holes = grid.params.copy()
         holes[50, 1] = -1.0  # a skipped pair as the driver marks it
         got = eng.sweep(holes)
@@ -608,3 +613,42 @@ def test_run_table_first_pass_device_api_full_sizes():
             a, b = a.cpu().numpy()[0], b.cpu().numpy()[0]
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
         assert int(np.argmax(a)) == int(np.argmax(b)) == 1 * 64 + 32
+
+
+def test_fused_pass_full_size_properties_and_oracle():
+    """The fused pipeline at 512^2 on a twist-major grid with Csym 1, 3, 6: equals the transform pipeline,
+    recovers the truth, is bit-reproducible, does not depend on the launch size, scores a clean image 1, and
+    agrees with the oracle on sampled candidates of every Csym."""
+    n, apix = 512, 1.0
+    d, br = 0.4 * n * apix, 2 * apix
+    from helicon_amd.grid import build_grid
+    twists = 1.20 + 0.01 * np.arange(-3, 4)
+    rises = 4.75 + 0.005 * np.arange(-9, 10)          # 19 per run: groups of 16 + 3
+    grid = build_grid(twists, rises, (1, 3, 6), tube_length=n * apix)
+    truth = (0 * 7 + 3) * 19 + 9
+    with H.SweepEngine(n) as eng, H.SweepEngine(n, max_batch=40) as small:
+        for e in (eng, small):
+            e.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        clean = eng.simulate(1.20, 4.75, 1)
+        eng.set_reference(clean)
+        s_clean = eng.sweep(grid.params)[0]
+        assert eng.last_first_pass == "fused"
+        assert s_clean[truth] == pytest.approx(1.0, abs=2e-5) and int(np.argmax(s_clean)) == truth
+        noisy = (clean + np.random.default_rng(1).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
+        eng.set_reference(noisy)
+        small.set_reference(noisy)
+        s1 = eng.sweep(grid.params)[0]
+        assert np.array_equal(s1, eng.sweep(grid.params)[0])            # bit-reproducible
+        eng.set_table_path(0)
+        s0 = eng.sweep(grid.params)[0]
+        assert eng.last_first_pass == "transform"
+        eng.set_table_path(2)
+        small.set_table_path(1)                                          # run tables, 40-candidate batches
+        s2 = small.sweep(grid.params)[0]
+        assert small.last_first_pass == "run_tables"
+    np.testing.assert_allclose(s1, s0, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(s1, s2, rtol=0, atol=2e-5)
+    assert int(np.argmax(s1)) == int(np.argmax(s0)) == truth
+    pick = np.array([truth, 5, 19 * 7 + 30, 2 * 19 * 7 + 100, 19 * 7 * 3 - 1])
+    ref = O.sweep_cpu(noisy, grid.params[pick, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(s1[pick], ref, rtol=0, atol=SCORE_TOL)
