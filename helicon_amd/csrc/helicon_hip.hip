@@ -1656,7 +1656,24 @@ __global__ void k_finalize_segments(const double* __restrict__ partials, int nbl
     s1 += partials[((size_t)cand * nblk + k) * 3];
     s2 += partials[((size_t)cand * nblk + k) * 3 + 1];
   }
-  for (int r = 0; r < rows; ++r) s3 += (double)part[((size_t)r * Bp + cand) * Sp + s];
+  {
+    // rows independent loads in flight (a serial loop of dependent waits cost 60 us per batch)
+    const float* const p0 = part + (size_t)cand * Sp + s;
+    const size_t stride = (size_t)Bp * Sp;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p0[(size_t)(r + j) * stride];
+      a0 += (double)v[0] + (double)v[4];
+      a1 += (double)v[1] + (double)v[5];
+      a2 += (double)v[2] + (double)v[6];
+      a3 += (double)v[3] + (double)v[7];
+    }
+    for (; r < rows; ++r) a0 += (double)p0[(size_t)r * stride];
+    s3 = (a0 + a1) + (a2 + a3);
+  }
   const RefConsts c = rc[s];
   double score = 0.0;
   if (c.sw > 0) {
