@@ -4,7 +4,8 @@ Python signatures.  Hand-written gfx950 kernels in ``csrc/``, reached through th
 from .grid import (CandidateGrid, build_grid, layer_line_mask, radial_band_mask, set_to_periodic_range,
                    shard_bounds, sweep_axis)
 from .denovo3D import (SweepEngine, SweepResult, apply_helical_symmetry, compute_power_spectra, cosine_similarity,
-                       cross_correlation_coefficient, process_one_task, simulate_helical_projection, sweep)
+                       cross_correlation_coefficient, low_high_pass_filter, process_one_task,
+                       simulate_helical_projection, sweep, threshold_data)
 from ._lib import HeliconHipError
 
 __version__ = "0.1.0"

@@ -1756,6 +1756,104 @@ __global__ void k_pair_sums(const T* __restrict__ x, const T* __restrict__ y, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Pre-sweep image preparation: Gaussian low / high pass in Fourier space
+// [filters.py:314-372] and threshold_data [filters.py:283-311].  The forward transform is the sweep's
+// own (k_first_pass<MODE_IMAGE> + k_second_pass<EPI_STORE>: half-plane spectrum [N/2+1][N]); the two
+// kernels below multiply by the filter and transform back: rows along x (complex), then columns along y
+// with two real output columns packed into one complex transform (the inverse of the first pass's trick).
+// An inverse transform is the forward one on conjugated data, conjugated again.
+// ------------------------------------------------------------------------------------------
+// filter value at unshifted frequency indices (ky, kx) [filters.py:343-369: the fftshifted meshgrid in
+// float32, then exp(-f2 R2) and 1 - exp(-f2 R2)]
+__device__ __forceinline__ float pass_filter(int ky, int kx, int n, float f2_lp, float f2_hp) {
+  const int fy = ky < n / 2 ? ky : ky - n, fx = kx < n / 2 ? kx : kx - n;
+  const float y = (float)fy / (float)(n / 2), x = (float)fx / (float)(n / 2);
+  const float r2 = x * x + y * y;
+  float f = 1.f;
+  if (f2_lp > 0.f) f *= expf(-f2_lp * r2);
+  if (f2_hp > 0.f) f *= 1.0f - expf(-f2_hp * r2);
+  return f;
+}
+
+// one workgroup = one transform: row ky of the half-plane spectrum, filtered, inverse-transformed along x
+template <int N>
+__global__ __launch_bounds__(N / 8) void k_filter_rows(const float2* __restrict__ spec, const float2* __restrict__ twtab,
+                                                        float f2_lp, float f2_hp, float2* __restrict__ out) {
+  constexpr int T = N / 8;
+  __shared__ __attribute__((aligned(16))) float2 buf[N];
+  const int t = threadIdx.x, ky = blockIdx.x;
+  float2 tw[TwN<N>::total];
+  load_twiddles<N>(tw, t, twtab);
+  const TwRegs twsrc{tw};
+  float2 v[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int kx = t + m * T;
+    const float2 f = spec[(size_t)ky * N + kx];
+    const float w = pass_filter(ky, kx, N, f2_lp, f2_hp);
+    v[m] = make_float2(w * f.x, -w * f.y);  // conj
+  }
+  fft_lanes<N>(v, twsrc, t, buf);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) out[(size_t)ky * N + t + m * T] = make_float2(v[m].x, -v[m].y);  // conj back (unscaled)
+}
+
+// one workgroup = one pair of image columns (xa, xa + 1): Z[ky] = Ga[ky] + i Gb[ky] over all N ky
+// (Hermitian extension of the half plane), inverse transform along y, a = Re z, b = Im z, scaled by 1/N^2
+template <int N>
+__global__ __launch_bounds__(N / 8) void k_inverse_cols(const float2* __restrict__ g, const float2* __restrict__ twtab,
+                                                         float* __restrict__ image) {
+  constexpr int T = N / 8;
+  __shared__ __attribute__((aligned(16))) float2 buf[N];
+  const int t = threadIdx.x, xa = 2 * blockIdx.x;
+  float2 tw[TwN<N>::total];
+  load_twiddles<N>(tw, t, twtab);
+  const TwRegs twsrc{tw};
+  float2 v[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int ky = t + m * T;
+    const bool mirror = ky > N / 2;
+    const int src = mirror ? N - ky : ky;
+    const float4 ab = *reinterpret_cast<const float4*>(g + (size_t)src * N + xa);  // Ga, Gb of row src
+    // mirrored rows: G[ky][x] = conj(G[N - ky][x]) (the filtered image is real)
+    const float2 ga = make_float2(ab.x, mirror ? -ab.y : ab.y), gb = make_float2(ab.z, mirror ? -ab.w : ab.w);
+    const float2 z = make_float2(ga.x - gb.y, ga.y + gb.x);  // Ga + i Gb
+    v[m] = make_float2(z.x, -z.y);                            // conj
+  }
+  fft_lanes<N>(v, twsrc, t, buf);
+  const float scale = 1.0f / ((float)N * (float)N);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int y = t + m * T;
+    *reinterpret_cast<float2*>(image + (size_t)y * N + xa) = make_float2(v[m].x * scale, -v[m].y * scale);
+  }
+}
+
+// threshold_data: max over the array (non-negative-safe float ordering via two atomics), then clip - thresh
+__global__ void k_array_max(const float* __restrict__ x, size_t n, int* __restrict__ out /*[2]: max of >=0 as int, min of <0 as uint*/) {
+  float m = -INFINITY;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, x[i]);
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    // float bits order like signed ints for non-negative values and reversed for negative ones
+    if (m >= 0.f) atomicMax(&out[0], __float_as_int(m));
+    else atomicMin(reinterpret_cast<unsigned*>(&out[1]), __float_as_uint(m));
+  }
+}
+
+__global__ void k_threshold(const float* __restrict__ x, size_t n, const int* __restrict__ mx, float fraction, float value,
+                            int use_fraction, float* __restrict__ out) {
+  float thresh = value;
+  if (use_fraction) {
+    const float vmax = mx[0] >= 0 ? __int_as_float(mx[0]) : __uint_as_float((unsigned)mx[1]);
+    thresh = vmax * fraction;
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = fmaxf(x[i], thresh) - thresh;  // np.clip(data, thresh, None) - thresh
+}
+
+// ------------------------------------------------------------------------------------------
 // apply_helical_symmetry (reference: lib/transforms.py:58-165): every output voxel gathers, for
 // each helical repeat hi in [-hmax, hmax] and cyclic copy ci, the trilinearly interpolated input
 // at the symmetry-related position and averages.  One thread per output voxel; coordinates and
@@ -2573,6 +2671,14 @@ int check_ready(hh_ctx* c, bool need_ref) {
   return HH_OK;
 }
 
+template <int N>
+int launch_filter(hh_ctx* c, float f2_lp, float f2_hp, const float2* spec, float2* rows, float* image) {
+  hipLaunchKernelGGL((k_filter_rows<N>), dim3(N / 2 + 1), dim3(N / 8), 0, c->stream, spec, c->d_tw, f2_lp, f2_hp, rows);
+  hipLaunchKernelGGL((k_inverse_cols<N>), dim3(N / 2), dim3(N / 8), 0, c->stream, rows, c->d_tw, image);
+  HH_HIP(c, hipGetLastError());
+  return HH_OK;
+}
+
 template <typename T>
 int pair_reduce(hh_ctx* c, const T* a, const T* b, int64_t n, double mx, double my, double out[5]) {
   const int grid = (int)std::min<int64_t>(1024, (n + 255) / 256);
@@ -3068,6 +3174,60 @@ int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_ou
   }
   (void)hipFree(d_mm);
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_power_spectrum: ") + hipGetErrorString(e));
+  return HH_OK;
+}
+
+int hh_low_high_pass_filter(hh_ctx* c, const float* image, double low_pass_fraction, double high_pass_fraction,
+                            float* out) {
+  if (!c || !image || !out) return fail(c, HH_ERR_ARG, "hh_low_high_pass_filter: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  const int n = c->n;
+  const size_t npix = (size_t)n * n, nh = (size_t)(n / 2 + 1) * n;
+  int rc = ensure_img(c, 2);  // [0] input, [1] output
+  if (rc) return rc;
+  rc = ensure_spec(c, 2);     // [0] spectrum, [1] rows after the inverse transform along x
+  if (rc) return rc;
+  HH_HIP(c, hipMemcpyAsync(c->d_img, image, npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  rc = spectra_of_images(c, 1);
+  if (rc) return rc;
+  // filters.py:362-369: each filter applies only for a fraction strictly inside (0, 1)
+  const bool lp = low_pass_fraction > 0 && low_pass_fraction < 1, hp = high_pass_fraction > 0 && high_pass_fraction < 1;
+  const float f2_lp = lp ? (float)(std::log(2.0) / (low_pass_fraction * low_pass_fraction)) : 0.f;
+  const float f2_hp = hp ? (float)(std::log(2.0) / (high_pass_fraction * high_pass_fraction)) : 0.f;
+  float* const d_out = c->d_img + npix;
+#define HH_CALL(NN) launch_filter<NN>(c, f2_lp, f2_hp, c->d_spec, c->d_spec + nh, d_out)
+  rc = [&]() -> int { HH_SWITCH_N(c, HH_CALL); }();
+#undef HH_CALL
+  if (rc) return rc;
+  HH_HIP(c, hipMemcpyAsync(out, d_out, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HH_HIP(c, hipStreamSynchronize(c->stream));
+  return HH_OK;
+}
+
+int hh_threshold_data(hh_ctx* c, const float* data, int64_t n, int use_fraction, double thresh, float* out) {
+  if (!c || !data || !out || n <= 0) return fail(c, HH_ERR_ARG, "hh_threshold_data: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  float *d_x = nullptr, *d_y = nullptr;
+  int* d_mx = nullptr;
+  HH_HIP(c, hipMalloc(&d_x, (size_t)n * sizeof(float)));
+  hipError_t e = hipMalloc(&d_y, (size_t)n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_mx, 2 * sizeof(int));
+  const int init[2] = {(int)0x80000000, -1};  // below every non-negative float's bits; above every negative float's (as unsigned)
+  if (e == hipSuccess) e = hipMemcpyAsync(d_x, data, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_mx, init, sizeof(init), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    const int grid = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    if (use_fraction) hipLaunchKernelGGL(k_array_max, dim3(grid), dim3(256), 0, c->stream, d_x, (size_t)n, d_mx);
+    hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(256), 0, c->stream, d_x, (size_t)n, d_mx, (float)thresh, (float)thresh,
+                       use_fraction ? 1 : 0, d_y);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_y, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_x);
+  (void)hipFree(d_y);
+  (void)hipFree(d_mx);
+  if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_threshold_data: ") + hipGetErrorString(e));
   return HH_OK;
 }
 

@@ -32,6 +32,8 @@ __all__ = [
     "cross_correlation_coefficient",
     "cosine_similarity",
     "process_one_task",
+    "low_high_pass_filter",
+    "threshold_data",
     "apply_helical_symmetry",
     "units_to_cylindrical",
 ]
@@ -209,6 +211,29 @@ class SweepEngine:
                                                   _ptr(phase, C.c_float) if want_phase else None))
         return pwr, phase
 
+    def low_high_pass_filter(self, image, low_pass_fraction=0.0, high_pass_fraction=0.0) -> np.ndarray:
+        img = _f32(image)
+        if img.shape != (self.n, self.n):
+            raise ValueError(f"image must be [{self.n}, {self.n}]")
+        out = np.empty_like(img)
+        with self._lock:
+            self._check(self._L.hh_low_high_pass_filter(self._ctx, _ptr(img, C.c_float), float(low_pass_fraction),
+                                                        float(high_pass_fraction), _ptr(out, C.c_float)))
+        return out
+
+    def threshold_data(self, data, thresh_fraction=None, thresh_value=None) -> np.ndarray:
+        x = _f32(data)
+        if thresh_fraction is not None and thresh_fraction >= 0:  # filters.py:303-309
+            use, thr = 1, float(thresh_fraction)
+        elif thresh_value is not None:
+            use, thr = 0, float(thresh_value)
+        else:
+            return x
+        out = np.empty_like(x)
+        with self._lock:
+            self._check(self._L.hh_threshold_data(self._ctx, _ptr(x, C.c_float), x.size, use, thr, _ptr(out, C.c_float)))
+        return out
+
     def _pair(self, a, b, f32name, f64name):
         a = np.asarray(a)
         b = np.asarray(b)
@@ -330,6 +355,29 @@ def cosine_similarity(a, b, *, device=0):
     return _engine(64, device).cosine_similarity(a, b)
 
 
+def low_high_pass_filter(data, low_pass_fraction=0, high_pass_fraction=0, *, device=0):
+    """``helicon.low_high_pass_filter`` (lib/filters.py:314-372) for a square power-of-two 2-D image:
+    Gaussian low / high pass in Fourier space on the device, float32 arithmetic, float64 result like
+    the reference's.  3-D input is outside the accelerated path."""
+    d = np.asarray(data)
+    if d.ndim == 3:
+        raise NotImplementedError("3-D low_high_pass_filter is outside the accelerated path")
+    if d.ndim != 2:
+        raise ValueError("Input data must be a 2D or 3D array.")  # filters.py:336-337
+    side = _square_side(*d.shape)
+    return _engine(side, device).low_high_pass_filter(d, low_pass_fraction, high_pass_fraction).astype(np.float64)
+
+
+def threshold_data(data, thresh_fraction=None, thresh_value=None, *, device=0):
+    """``helicon.threshold_data`` (lib/filters.py:283-311) on the device; returns the input unchanged
+    when neither threshold applies, like the reference."""
+    d = np.asarray(data)
+    if not ((thresh_fraction is not None and thresh_fraction >= 0) or thresh_value is not None):
+        return data
+    eng = _engine(32, device)  # the kernel does not depend on the image side; any context of the device serves
+    return eng.threshold_data(d, thresh_fraction, thresh_value).astype(d.dtype if d.dtype.kind == "f" else np.float64)
+
+
 def apply_helical_symmetry(data, apix, twist_degree, rise_angstrom, csym=1, fraction=1.0, new_size=None,
                            new_apix=None, cpu=1, *, device=0, return_kernel_ms=False):
     """transforms.py:58-74 (same positional signature; ``cpu`` is accepted and ignored).  ``new_size=None``
@@ -425,16 +473,26 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
     data = np.asarray(data)
     if np.std(data) == 0:
         return None
-    if denoise or (low_pass is not None and low_pass > 0) or horizontalize:
-        raise NotImplementedError("denoise / low_pass / horizontalize are outside the accelerated path")
+    if denoise or horizontalize:
+        raise NotImplementedError("denoise / horizontalize need scikit-image and are outside the accelerated path")
     if target_apix2d is not None and target_apix2d > 0 and abs(target_apix2d - apix2d_orig) > 1e-6:
         raise NotImplementedError("rescaling to target_apix2d is outside the accelerated path")
-    if transpose:
+    apix = float(apix2d_orig)
+    opts = dict(algorithm or {})
+    if low_pass is not None and low_pass > 2 * apix:  # pipeline.py:183-188
+        data = low_high_pass_filter(data, low_pass_fraction=2 * apix / low_pass,
+                                    high_pass_fraction=2.0 / np.max(data.shape), device=int(opts.get("device", 0)))
+    if transpose is not None and transpose > 0:  # pipeline.py:202-203 (transpose < 0 = "if vertical" needs is_vertical)
         data = data.T
     ny, nx = data.shape
     side = _square_side(ny, nx)
-    apix = float(apix2d_orig)
-    opts = dict(algorithm or {})
+    if thresh_fraction is not None and thresh_fraction >= 0:  # pipeline.py:277-284
+        # pipeline.py:253-255: reconstruct_diameter = tube_diameter if 0 < tube_diameter < ny*apix else ny*apix
+        rec_d = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
+        nr = min(ny // 2 - 1, int(np.ceil(rec_d / 2 / apix) + 1))
+        data = np.asarray(data, dtype=np.float64) - np.median(np.asarray(data)[(ny // 2 - nr, ny // 2 + nr), :])
+        data = threshold_data(data, thresh_fraction=thresh_fraction, device=int(opts.get("device", 0)))
+        data = data / np.max(data)
     diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))
     ball_radius = float(opts.get("ball_radius", 2.0 * apix))
     eng = _engine(side, int(opts.get("device", 0)))

@@ -133,6 +133,16 @@ int hh_set_table_path(hh_ctx* ctx, int mode);
  * second pass, 1 = run tables + second pass, 2 = fused. */
 int hh_last_first_pass(const hh_ctx* ctx);
 
+/* Pre-sweep image preparation on the device.
+ * hh_low_high_pass_filter: helicon.low_high_pass_filter (lib/filters.py:314-372) for one N x N float32 image
+ * (host in, host out): Gaussian low pass exp(-ln2 R^2 / lp^2) and / or high pass 1 - exp(-ln2 R^2 / hp^2),
+ * R = radius as a fraction of Nyquist; a fraction outside (0, 1) switches that filter off.
+ * hh_threshold_data: helicon.threshold_data (lib/filters.py:283-311): out = clip(data, t, None) - t with
+ * t = max(data) * thresh (use_fraction != 0) or t = thresh. */
+int hh_low_high_pass_filter(hh_ctx* ctx, const float* image, double low_pass_fraction, double high_pass_fraction,
+                            float* out);
+int hh_threshold_data(hh_ctx* ctx, const float* data, int64_t n, int use_fraction, double thresh, float* out);
+
 /* arg-max with ties resolved to the lowest index (np.argmax); NaN never wins. */
 int hh_argmax(const float* scores, int64_t n, int64_t* index);
 

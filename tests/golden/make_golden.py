@@ -138,6 +138,16 @@ def g6_filters():
     arrs["lp"] = filters.low_high_pass_filter(x, low_pass_fraction=0.3)
     arrs["hp"] = filters.low_high_pass_filter(x, high_pass_fraction=0.1)
     arrs["lphp"] = filters.low_high_pass_filter(x, low_pass_fraction=0.5, high_pass_fraction=0.05)
+    # a second, larger image (the device path serves power-of-two sides 32..1024) with the pipeline's own
+    # fractions (pipeline.py:183-188: low_pass 20 A at 2 A/pixel, high pass 2 / side)
+    x64 = np.random.default_rng(66).normal(size=(64, 64)).astype(np.float32)
+    arrs["x64"] = x64
+    arrs["x64_lphp"] = filters.low_high_pass_filter(x64, low_pass_fraction=0.2, high_pass_fraction=2.0 / 64)
+    arrs["thr_frac_0.2"] = filters.threshold_data(x, thresh_fraction=0.2)
+    arrs["thr_frac_0"] = filters.threshold_data(x, thresh_fraction=0.0)
+    arrs["thr_value_0.5"] = filters.threshold_data(x, thresh_value=0.5)
+    arrs["thr_neg_in"] = -np.abs(x) - 0.25
+    arrs["thr_neg_frac_0.5"] = filters.threshold_data(arrs["thr_neg_in"], thresh_fraction=0.5)
     arrs["norm_0_100"] = filters.normalize_percentile(x, (0, 100))
     arrs["norm_10_90"] = filters.normalize_percentile(x, (10, 90))
     arrs["periodic_in"] = np.asarray([-540.0, -181.0, -180.0, -0.5, 0.0, 179.99, 180.0, 180.5, 359.0, 725.0])

@@ -652,3 +652,57 @@ def test_fused_pass_full_size_properties_and_oracle():
     pick = np.array([truth, 5, 19 * 7 + 30, 2 * 19 * 7 + 100, 19 * 7 * 3 - 1])
     ref = O.sweep_cpu(noisy, grid.params[pick, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
     np.testing.assert_allclose(s1[pick], ref, rtol=0, atol=SCORE_TOL)
+
+
+# ---------------------------------------------------------------------------- image preparation on the device
+def test_low_high_pass_filter_and_threshold_match_golden_and_oracle(golden_dir):
+    """helicon.low_high_pass_filter / threshold_data on the device against the reference's own outputs (G6)
+    and against the oracle at the sweep's sizes.  float32 transforms: 2e-6 of the image's amplitude."""
+    g = np.load(golden_dir / "g6_filters.npz")
+    x = g["x"]
+    for kw, key in ((dict(low_pass_fraction=0.3), "lp"), (dict(high_pass_fraction=0.1), "hp"),
+                    (dict(low_pass_fraction=0.5, high_pass_fraction=0.05), "lphp")):
+        out = H.low_high_pass_filter(x, **kw)
+        assert out.shape == x.shape and out.dtype == np.float64
+        np.testing.assert_allclose(out, g[key], rtol=0, atol=2e-6 * np.abs(x).max(), err_msg=key)
+    np.testing.assert_allclose(H.low_high_pass_filter(g["x64"], 0.2, 2.0 / 64), g["x64_lphp"], rtol=0, atol=1e-5)
+    # fractions outside (0, 1) switch a filter off: the image comes back (filters.py:362-369)
+    np.testing.assert_allclose(H.low_high_pass_filter(x, 0, 0), x, rtol=0, atol=2e-6 * np.abs(x).max())
+    np.testing.assert_allclose(H.low_high_pass_filter(x, 1.5, 0), x, rtol=0, atol=2e-6 * np.abs(x).max())
+    rng = np.random.default_rng(9)
+    for n in (128, 512, 1024):
+        img = rng.normal(size=(n, n)).astype(np.float32) + 3.0
+        ref = O.low_high_pass_filter(img.astype(np.float64), 0.25, 2.0 / n)
+        np.testing.assert_allclose(H.low_high_pass_filter(img, 0.25, 2.0 / n), ref, rtol=0, atol=1e-5 * np.abs(img).max())
+    with pytest.raises(ValueError):
+        H.low_high_pass_filter(np.zeros((48, 48)))          # not a supported side
+    with pytest.raises(NotImplementedError):
+        H.low_high_pass_filter(np.zeros((32, 32, 32)))
+    with pytest.raises(ValueError):
+        H.low_high_pass_filter(np.zeros(32))                # filters.py:336-337
+
+    assert np.allclose(H.threshold_data(x, thresh_fraction=0.2), g["thr_frac_0.2"], rtol=0, atol=1e-6)
+    assert np.allclose(H.threshold_data(x, thresh_fraction=0.0), g["thr_frac_0"], rtol=0, atol=1e-6)
+    assert np.allclose(H.threshold_data(x, thresh_value=0.5), g["thr_value_0.5"], rtol=0, atol=1e-6)
+    assert np.allclose(H.threshold_data(g["thr_neg_in"], thresh_fraction=0.5), g["thr_neg_frac_0.5"], rtol=0, atol=1e-6)
+    assert H.threshold_data(x) is x and H.threshold_data(x, thresh_fraction=-1) is x
+    big = rng.normal(size=(1024, 1024)).astype(np.float32)
+    assert np.array_equal(H.threshold_data(big, thresh_fraction=0.3), O.threshold_data(big, thresh_fraction=np.float32(0.3)))
+
+
+def test_process_one_task_with_low_pass_and_threshold():
+    """The reference's image preparation inside process_one_task (pipeline.py:183-188, 277-284) on the device
+    path: same score as preparing the image with the oracle's functions first."""
+    n, apix = 64, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1, seed=4)
+    args = [0, 1, img, "f", 0, 29.0, 10.0, 0, 1, 0, 0, 0, 0, 0, 0, apix, "", 20.0, 0, 0,
+            -1, -1, 0.1, -1, n * apix, n * apix, 0.0, 30.0, -1, "linear", 0, 0, "cosine",
+            dict(helical_diameter=d, ball_radius=br), 0]
+    score, ret, meta = H.process_one_task(*args)
+    prep = O.low_high_pass_filter(img.astype(np.float64), low_pass_fraction=2 * apix / 20.0, high_pass_fraction=2.0 / n)
+    nr = min(n // 2 - 1, int(np.ceil(n * apix / 2 / apix) + 1))
+    prep = prep - np.median(prep[(n // 2 - nr, n // 2 + nr), :])
+    prep = O.threshold_data(prep, thresh_fraction=0.1)
+    prep = prep / prep.max()
+    ref = O.sweep_cpu(prep, np.array([[29.0, 10.0, 1]]), O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)[0]
+    assert score == pytest.approx(ref, abs=5e-4)
