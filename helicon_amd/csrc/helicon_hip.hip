@@ -68,7 +68,7 @@
 #define HH_KF_CPW 16       // fused pass: candidates per workgroup
 #endif
 #ifndef HH_FUSED_BATCH
-#define HH_FUSED_BATCH 4096  // fused pass: candidates per launch (whole runs)
+#define HH_FUSED_BATCH 32768  // fused pass: candidates per launch (whole runs); 1.3 GB of column factors + moments at N = 512
 #endif
 #ifndef HH_KF_WPS
 #define HH_KF_WPS 4        // fused pass: waves per SIMD the register allocator must leave room for
