@@ -246,8 +246,8 @@ def roofline(prof, n, b_alg, pipeline):
     almost none of B_alg (`traffic` << `achieved` x time) and the same formula can exceed 1.0: the
     section-8d roofline does not bound it.  What bounds it is vector issue; `valu` prices the
     section-8d FLOP count (5 N^2 log2 N per candidate) against the fp32 vector peak.
-    `traffic` = measured bytes per batch from the calibrated FETCH_SIZE / WRITE_SIZE passes in
-    profiles/traffic.json."""
+    `traffic` = measured bytes per launch (bytes per candidate from the calibrated FETCH_SIZE /
+    WRITE_SIZE passes in profiles/traffic.json x the candidates of an average sampled launch)."""
     half = 8 * n * (n // 2 + 1)
     slots = (("ms_first_pass", "n_first_pass"), ("ms_second_pass", "n_second_pass"))
     cand = prof["candidates"]
@@ -265,9 +265,11 @@ def roofline(prof, n, b_alg, pipeline):
         if launches == 0:
             continue
         avg_us = 1e3 * prof[ms_key] / launches
-        entry = {"launches": launches, "avg_us": avg_us, "role": what, "traffic": measured.get(tkey)}
+        per_launch = cand / launches
+        per_cand = measured.get(tkey)  # measured bytes per candidate (profiles/traffic.json)
+        entry = {"launches": launches, "avg_us": avg_us, "role": what,
+                 "traffic": per_cand * per_launch if per_cand is not None else None}
         if pipeline != "fused":
-            per_launch = cand / launches
             gbps = half * per_launch / (avg_us * 1e-6) / 1e9
             entry.update({"candidates_per_launch": per_launch, "alg_bytes_per_candidate": half, "GBps": gbps,
                           "frac": gbps / (HBM_PEAK / 1e9)})

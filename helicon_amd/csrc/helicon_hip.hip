@@ -1608,39 +1608,71 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(64) void k_segment_corr(const float* __restrict__ q /*[Bp][K]*/,
-                                                     const float* __restrict__ wec /*[Sp][K]*/, int n_k /*N*/,
-                                                     size_t K, int Bp, int Sp, float* __restrict__ part /*[rows][Bp][Sp]*/) {
-  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+// A workgroup of four wavefronts owns up to 256 candidates x 64 segments of ONE spectrum row (n_k bins):
+// the operands are staged through LDS in slices of 32 bins with whole-line global loads (eight lanes per
+// 128-byte line; reading them straight from global put every lane of a load on a different row and
+// thrashed the L1), the next slice's loads fly under the current slice's MFMAs.
+constexpr int SC_KC = 32;            // bins per staged slice
+constexpr int SC_LD = SC_KC + 4;     // LDS row stride in floats (16-byte aligned rows)
+
+__global__ __launch_bounds__(256) void k_segment_corr(const float* __restrict__ q /*[Bp][K]*/,
+                                                      const float* __restrict__ wec /*[Sp][K]*/, int n_k /*N*/,
+                                                      size_t K, int Bp, int Sp, float* __restrict__ part /*[rows][Bp][Sp]*/) {
+  __shared__ __attribute__((aligned(16))) float sA[256 * SC_LD];
+  __shared__ __attribute__((aligned(16))) float sB[64 * SC_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int row = blockIdx.x;                 // spectrum row = K-slice of n_k bins
-  const int c0 = blockIdx.y * 64, s0 = blockIdx.z * 64;
-  const float* qa = q + (size_t)(c0 + i) * K + (size_t)row * n_k + 4 * h;
-  const float* qb = qa + (size_t)32 * K;
-  const float* wa = wec + (size_t)(s0 + i) * K + (size_t)row * n_k + 4 * h;
-  const float* wb = wa + (size_t)32 * K;
+  const int c0 = blockIdx.y * 256, s0 = blockIdx.z * 64;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: thread covers 16 bytes of rows lr + 32 j
+  const int na = min(256, Bp - c0);             // candidate rows that exist (Bp is a multiple of 64)
+  const float* const qbase = q + (size_t)c0 * K + (size_t)row * n_k + lc;
+  const float* const wbase = wec + (size_t)s0 * K + (size_t)row * n_k + lc;
+  float4 ra[8], rb[2];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = lr + 32 * j;
+      ra[j] = r < na ? *reinterpret_cast<const float4*>(qbase + (size_t)r * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rb[j] = *reinterpret_cast<const float4*>(wbase + (size_t)(lr + 32 * j) * K + k);
+  };
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  for (int k = 0; k < n_k; k += 8) {
-    const float4 a0 = *reinterpret_cast<const float4*>(qa + k), a1 = *reinterpret_cast<const float4*>(qb + k);
-    const float4 b0 = *reinterpret_cast<const float4*>(wa + k), b1 = *reinterpret_cast<const float4*>(wb + k);
-    // lane (i, h) supplies A[i][kk] and B[kk][i] for kk = k + 4h + j in step j: both operands use
-    // the same k numbering, which is all a dot product needs
-#define HH_STEP(C)                                                         \
-  acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b0.C, acc00, 0, 0, 0); \
-  acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b1.C, acc01, 0, 0, 0); \
-  acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b0.C, acc10, 0, 0, 0); \
-  acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b1.C, acc11, 0, 0, 0);
-    HH_STEP(x) HH_STEP(y) HH_STEP(z) HH_STEP(w)
-#undef HH_STEP
+  fetch(0);
+  for (int k = 0; k < n_k; k += SC_KC) {
+    __syncthreads();  // the previous slice has been consumed
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(sA + (lr + 32 * j) * SC_LD + lc) = ra[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(sB + (lr + 32 * j) * SC_LD + lc) = rb[j];
+    __syncthreads();
+    if (k + SC_KC < n_k) fetch(k + SC_KC);
+    const float* const a0p = sA + (wave * 64 + i) * SC_LD + h;
+    const float* const a1p = a0p + 32 * SC_LD;
+    const float* const b0p = sB + i * SC_LD + h;
+    const float* const b1p = b0p + 32 * SC_LD;
+    // lane (i, h) supplies A[i][kk + h] and B[kk + h][i]: both operands use the same k numbering,
+    // which is all a dot product needs
+#pragma unroll
+    for (int kk = 0; kk < SC_KC; kk += 2) {
+      const float a0 = a0p[kk], a1 = a1p[kk], b0 = b0p[kk], b1 = b1p[kk];
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+    }
   }
   // D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int cw = c0 + wave * 64;
+  if (cw >= Bp) return;
   float* const out = part + (size_t)row * Bp * Sp;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
-    out[(size_t)(c0 + ci) * Sp + s0 + i] = acc00[r];
-    out[(size_t)(c0 + ci) * Sp + s0 + 32 + i] = acc01[r];
-    out[(size_t)(c0 + 32 + ci) * Sp + s0 + i] = acc10[r];
-    out[(size_t)(c0 + 32 + ci) * Sp + s0 + 32 + i] = acc11[r];
+    out[(size_t)(cw + ci) * Sp + s0 + i] = acc00[r];
+    out[(size_t)(cw + ci) * Sp + s0 + 32 + i] = acc01[r];
+    out[(size_t)(cw + 32 + ci) * Sp + s0 + i] = acc10[r];
+    out[(size_t)(cw + 32 + ci) * Sp + s0 + 32 + i] = acc11[r];
   }
 }
 
@@ -2330,7 +2362,7 @@ int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, bool last, float* d_sc
     const int rows = c->n / 2 + 1;
     const size_t K = (size_t)rows * c->n;
     ProfScope ps(c, 2);
-    hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 63) / 64, c->s_pad / 64), dim3(64), 0, c->stream, c->d_q,
+    hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 255) / 256, c->s_pad / 64), dim3(256), 0, c->stream, c->d_q,
                        c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
     const int total = nb * c->n_segments;
     hipLaunchKernelGGL(k_sum_partials, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, c->stream, partials, npart,

@@ -13,6 +13,7 @@ from collections import defaultdict
 from pathlib import Path
 
 CALIB_BYTES = 1 << 30
+SWEEP_CANDIDATES = 100000
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -56,10 +57,16 @@ def main(fetch_dir, write_dir, n=512, batch=256, out=None):
             wv, wl = pick(write, frag)
         except KeyError:
             continue
+        # tools/traffic_run.py sweeps the 100k-candidate C2 grid once per pipeline; k_second_pass serves two of them
+        cands = SWEEP_CANDIDATES * (2 if name == "second_pass" else 1)
+        total = (fv * f_unit + wv * w_unit) * fl
         kernels[name] = {"launches": fl, "FETCH_SIZE": fv, "WRITE_SIZE": wv,
                          "read_bytes_per_launch": fv * f_unit, "write_bytes_per_launch": wv * w_unit,
-                         "bytes_per_launch": fv * f_unit + wv * w_unit}
-    res[f"n{n}"] = {k: v["bytes_per_launch"] for k, v in kernels.items()}
+                         "bytes_per_launch": fv * f_unit + wv * w_unit, "candidates": cands,
+                         "bytes_per_candidate": total / cands}
+    # launch sizes differ between pipelines (and the last launch of a sweep is short), so the figure bench.py
+    # uses is per candidate
+    res[f"n{n}"] = {k: v["bytes_per_candidate"] for k, v in kernels.items()}
     res[f"n{n}_detail"] = kernels
     out = Path(out) if out else ROOT / "profiles" / "traffic.json"
     out.write_text(json.dumps(res, indent=1) + "\n")
