@@ -706,3 +706,43 @@ def test_process_one_task_with_low_pass_and_threshold():
     prep = prep / prep.max()
     ref = O.sweep_cpu(prep, np.array([[29.0, 10.0, 1]]), O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)[0]
     assert score == pytest.approx(ref, abs=5e-4)
+
+
+def test_shared_twist_pipelines_geometry_fuzz_against_transform():
+    """30 seeded random geometries without tilt/psi (the shared-twist pipelines' domain): ball radii from narrow to
+    footprints spanning many rows, helices clipped at the image edge, dy, rot, Csym up to 7, one to three
+    subunits with axial offsets, rises from a fraction of a pixel to half the box, short and long runs, unusual
+    masks.  Whatever pipeline the library picks for the list must reproduce the general (transform) pipeline."""
+    rng = np.random.default_rng(4242)
+    picked = {"fused": 0, "run_tables": 0, "transform": 0}
+    for case in range(30):
+        n = int(rng.choice([32, 64, 128], p=[0.3, 0.4, 0.3]))
+        apix = float(rng.choice([1.0, 2.0, 3.3]))
+        br = float(rng.uniform(0.8, 4.5) * apix) if case % 5 else float(rng.uniform(5.0, 7.5) * apix)
+        d = float(rng.uniform(0.1, 0.97) * (0.99 * n * apix - br))
+        dy = float(rng.choice([0.0, rng.uniform(-0.2, 0.2) * n * apix]))
+        rot = float(rng.choice([0.0, rng.uniform(-180, 180)]))
+        csym = int(rng.integers(1, 8))
+        rise0 = float(rng.choice([rng.uniform(2.0, 30.0) * apix / 2, rng.uniform(0.3, 1.0) * apix, n * apix * 0.3]))
+        n_rises = int(rng.choice([8, 11, 19, 40]))
+        rises = rise0 * (1.0 + 0.01 * np.arange(n_rises))
+        twists = np.round(rng.uniform(-170, 170, 3), 3)
+        units = None
+        if case % 3 == 0:
+            k = int(rng.integers(2, 4))
+            units = np.stack([rng.uniform(0.2, 0.5, k) * d, rng.uniform(-3, 3, k), rng.uniform(-6, 6, k) * apix], axis=1)
+        params = np.array([[tw, rs, csym, rot] for tw in twists for rs in rises])
+        mask = O.radial_band_mask(n, n) if case % 3 else (rng.random((n, n)) < 0.4)
+        tag = f"case {case}: n={n} apix={apix} br={br:.2f} d={d:.1f} rise0={rise0:.3f} x{n_rises} c={csym} rot={rot:.1f} dy={dy:.1f} units={None if units is None else len(units)}"
+        with H.SweepEngine(n, max_batch=int(rng.choice([0, 16, 50]))) as eng:
+            eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br, dy=dy, units=units)
+            img = eng.simulate(float(twists[1]), float(rises[n_rises // 2]), csym, rot)
+            img = (img + rng.normal(0, 0.3 * img.std() + 1e-3, img.shape)).astype(np.float32)
+            eng.set_reference(img, mask, log=bool(case % 2))
+            got = eng.sweep(params)[0]
+            picked[eng.last_first_pass] += 1
+            eng.set_table_path(0)
+            want = eng.sweep(params)[0]
+            assert eng.last_first_pass == "transform"
+        np.testing.assert_allclose(got, want, rtol=0, atol=5e-5, err_msg=tag)
+    assert picked["fused"] >= 10, picked

@@ -144,3 +144,26 @@ def test_mrc_round_trip_and_reader_errors(tmp_path):
     data, apix = mrc.read_mrc(tmp_path / "b.mrc")
     assert apix == pytest.approx(2.0)
     np.testing.assert_array_equal(np.asarray(data), np.arange(8).reshape(1, 2, 4))
+
+
+def test_bench_roofline_object_has_the_contract_keys_for_every_pipeline():
+    """bench.py's roofline() on canned profile numbers (no GPU): the keys the driver and the judge read."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b_alg = 4 * 512 * 512 + 16 * 512 * 257
+    prof = dict(ms_first_pass=12.0, n_first_pass=250, ms_second_pass=14.5, n_second_pass=250, ms_finalize=0.01,
+                n_finalize=1, ms_centres=0.2, n_centres=10, candidates=62500, candidates_total=1000000)
+    for pipeline in ("transform", "run_tables"):
+        r = bench.roofline(prof, 512, b_alg, pipeline)
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernels"} <= set(r)
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
+        assert len(r["kernels"]) == 2 and all("avg_us" in k for k in r["kernels"].values())
+    fused = dict(prof, ms_first_pass=1.3, n_first_pass=10, ms_second_pass=250.0, n_second_pass=40, candidates=1000000)
+    r = bench.roofline(fused, 512, b_alg, "fused")
+    assert r["pipeline"] == "fused" and "k_fused_pass" in r["kernels"] and "valu" in r and "note" in r
+    assert r["frac"] > 1.0 > r["valu"]["frac"] > 0          # B_alg is not moved; the vector figure is the bound
+    assert r["traffic"] is None or r["traffic"] < 0.1 * b_alg * r["candidates_per_launch"]
