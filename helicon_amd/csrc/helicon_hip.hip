@@ -413,8 +413,25 @@ __device__ __forceinline__ float pearson_from_moments(double s1, double s2, doub
 __device__ __forceinline__ void team_moments(const double* __restrict__ partials, int npart, int64_t i, int lane,
                                              int team, double& s1, double& s2, double& s3) {
   s1 = s2 = s3 = 0;
-  for (int k = lane; k < npart; k += team) {
-    const double* p = partials + (i * npart + k) * 3;
+  // the triples were written by another kernel a moment ago (HBM / Infinity Cache latency): keep a lane's loads
+  // in flight together instead of waiting for each slot in turn
+  const double* const base = partials + i * npart * 3;
+  int k = lane;
+  for (; k + 3 * team < npart; k += 4 * team) {
+    double v[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) v[j][e] = base[(size_t)(k + j * team) * 3 + e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1 += v[j][0];
+      s2 += v[j][1];
+      s3 += v[j][2];
+    }
+  }
+  for (; k < npart; k += team) {
+    const double* p = base + (size_t)k * 3;
     s1 += p[0];
     s2 += p[1];
     s3 += p[2];
