@@ -69,10 +69,12 @@ typedef struct hh_geom {
  * on the context's stream around every launch of every k-th batch of a sweep.  Event records
  * break the back-to-back issue of kernels (about 12 % of a sweep at k = 1), hence the sampling. */
 typedef struct hh_profile {
-  double ms_first_pass;    /* raster + column FFT kernel                               */
-  double ms_second_pass;   /* row FFT + |F| + log1p + masked moment reduction kernel   */
-  double ms_finalize;      /* Pearson from moments                                     */
-  double ms_centres;       /* lattice-centre kernel                                    */
+  double ms_first_pass;    /* first pass: k_first_pass / k_first_pass_table (fused: the
+                              stand-alone k_column_factors of a sweep's first batch)   */
+  double ms_second_pass;   /* k_second_pass, or k_fused_pass (build + row FFT + |F| +
+                              log1p + masked moment reduction)                         */
+  double ms_finalize;      /* Pearson from moments / several-segment contraction       */
+  double ms_centres;       /* k_run_table (run tables of the shared-twist pipelines)   */
   int64_t n_first_pass;    /* launches                                                 */
   int64_t n_second_pass;
   int64_t n_finalize;

@@ -746,3 +746,29 @@ def test_shared_twist_pipelines_geometry_fuzz_against_transform():
             assert eng.last_first_pass == "transform"
         np.testing.assert_allclose(got, want, rtol=0, atol=5e-5, err_msg=tag)
     assert picked["fused"] >= 10, picked
+
+
+def test_c2_full_grid_fused_sweep_spot_checked_against_oracle():
+    """The bench workload itself (BASELINE config 2: 512^2, 400 x 250 grid, Csym 1) through the default pipeline:
+    arg-max at the synthetic truth, 24 candidates drawn from the whole grid (plus the truth and its neighbours)
+    against the oracle, and the whole score grid against the general pipeline."""
+    from helicon_amd.grid import build_grid, sweep_axis
+    n, apix = 512, 1.0
+    img, d, br = _noisy_helix(n, apix, 1.20, 4.75, 1, seed=0)
+    grid = build_grid(sweep_axis(0.01, 4.00, 0.01), sweep_axis(4.000, 5.245, 0.005), (1,), tube_length=n * apix)
+    assert len(grid) == 100000 and grid.valid.all()
+    with H.SweepEngine(n) as eng:
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        eng.set_reference(img)
+        fused = eng.sweep(grid.params)[0]
+        assert eng.last_first_pass == "fused"
+        eng.set_table_path(0)
+        general = eng.sweep(grid.params)[0]
+    best = int(np.argmax(fused))
+    assert tuple(np.round(grid.params[best, :2], 6)) == (1.2, 4.75) and best == int(np.argmax(general))
+    np.testing.assert_allclose(fused, general, rtol=0, atol=2e-5)
+    rng = np.random.default_rng(7)
+    pick = np.unique(np.r_[best, best - 1, best + 1, best - 250, best + 250, rng.integers(0, len(grid), 24)])
+    ref = O.sweep_cpu(img, grid.params[pick, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
+    np.testing.assert_allclose(fused[pick], ref, rtol=0, atol=SCORE_TOL)
+    assert np.abs(fused[pick] - ref).max() < 2e-5
