@@ -70,6 +70,9 @@
 #ifndef HH_FUSED_BATCH
 #define HH_FUSED_BATCH 32768  // fused pass: candidates per launch (whole runs); 1.3 GB of column factors + moments at N = 512
 #endif
+#ifndef HH_SEG_BATCH
+#define HH_SEG_BATCH 1024   // fused pass with several segments: candidates per launch (q and the contraction's partials)
+#endif
 #ifndef HH_KF_WPS
 #define HH_KF_WPS 4        // fused pass: waves per SIMD the register allocator must leave room for
 #endif
@@ -2480,7 +2483,8 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   const int nky = c->n / 2;
   // The fused pass has no intermediate to hold, so its batches are not tied to max_batch: long
   // launches even out the tail of the grid (C2: 3.2 M candidates/s at 250 per launch, 3.8 M at 4000).
-  const int bmax = plan.fused && c->n_segments == 1 ? std::max(c->max_batch, HH_FUSED_BATCH) : c->max_batch;
+  const int bmax = !plan.fused ? c->max_batch
+                   : c->n_segments == 1 ? std::max(c->max_batch, HH_FUSED_BATCH) : std::max(c->max_batch, HH_SEG_BATCH);
   const int64_t per_batch = plan.len <= bmax ? bmax / plan.len : 1;
   const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
   int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
@@ -3025,7 +3029,9 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   // with several segments the centred spectra go to a [Sp][K] matrix for the MFMA contraction
   const bool multi = n_segments > 1;
   const int s_pad = multi ? (n_segments + 63) / 64 * 64 : 0;
-  const int b_pad = multi ? (c->max_batch + 63) / 64 * 64 : 0;
+  // several segments: the shared-twist pipelines batch up to HH_SEG_BATCH candidates (q of a batch lives in HBM:
+  // 0.5 MB per candidate at N = 512), the general pipeline max_batch
+  const int b_pad = multi ? (std::max(c->max_batch, HH_SEG_BATCH) + 63) / 64 * 64 : 0;
   std::vector<float2> w2(nh);
   std::vector<float> wecm(multi ? (size_t)s_pad * nh : 0, 0.f);
   c->ref.assign(n_segments, RefConsts{});
