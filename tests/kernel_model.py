@@ -122,3 +122,39 @@ def pearson_from_moments(q, e, w):
     if not den > 0:
         return 0.0
     return cov / np.sqrt(den)
+
+
+def run_table(n, apix, twist, csym, rot, diameter, ball_radius, imax, tail_bits=24):
+    """k_run_table: T[i + imax][ky] = sum over the csym copies s of G_(i,s)[ky], ky < N/2, with
+    G_c[ky] = sum_y ey_c(y) exp(-2 pi i ky y / N) over the truncated rows of subunit c's footprint; slot
+    ky = 0 packs (G[0], G[N/2]).  One subunit per asymmetric unit (radius diameter/2, azimuth 0, axial 0)."""
+    sigma2 = ball_radius ** 2 / np.log(2.0)
+    rpx = max(1, int(np.ceil(np.sqrt(sigma2 * tail_bits * np.log(2.0)) / apix)))
+    y = np.arange(n)
+    tab = np.zeros((2 * imax + 1, n // 2), dtype=np.complex128)
+    for i in range(-imax, imax + 1):
+        g_full = np.zeros(n, dtype=np.complex128)
+        for s in range(csym):
+            ang = np.deg2rad(rot + twist * i + 360.0 * s / csym)
+            yc = diameter / 2.0 * np.sin(ang)  # row coordinate: does not depend on the rise
+            cy = yc / apix + n // 2
+            rows = y[np.abs(y - cy) <= rpx]
+            ey = np.exp(-(((rows - n // 2) * apix - yc) ** 2) / sigma2)
+            g_full += (ey[None, :] * np.exp(-2j * np.pi * np.outer(np.arange(n), rows) / n)).sum(axis=1)
+        tab[i + imax] = g_full[: n // 2]
+        tab[i + imax, 0] = g_full[0].real + 1j * g_full[n // 2].real
+    return tab, rpx, sigma2
+
+
+def first_pass_from_table(tab, rpx, sigma2, n, apix, rise, imax_t):
+    """k_first_pass_table / the panel build of k_fused_pass: H[ky][x] = sum_i ex_i(x) T[i][ky] with the column
+    factor ex_i(x) = exp(-dx^2 / sigma^2) inside the truncation window around the axial coordinate i * rise."""
+    H = np.zeros((n // 2, n), dtype=np.complex128)
+    imax = int(np.ceil(n * apix / rise))  # utils.py:153
+    for i in range(-imax, imax + 1):
+        xc = i * rise
+        cx = xc / apix + n // 2
+        cols = np.arange(n)[np.abs(np.arange(n) - cx) <= rpx]
+        ex = np.exp(-(((cols - n // 2) * apix - xc) ** 2) / sigma2)
+        H[:, cols] += tab[i + imax_t][:, None] * ex[None, :]
+    return H

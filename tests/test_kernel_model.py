@@ -46,3 +46,21 @@ def test_half_plane_moments_equal_full_plane_masked_cc(N, kind):
     qs = np.log1p(np.abs(KM.second_pass(KM.first_pass(img_s))))
     assert KM.pearson_from_moments(qs, qe, W) == pytest.approx(ref, abs=1e-12)
     assert W.sum() == mask.sum()
+
+
+@pytest.mark.parametrize("csym,rot", [(1, 0.0), (3, 25.0)])
+def test_run_table_identity_gives_the_oracles_spectrum(csym, rot):
+    """The shared-twist pipelines' identity H[ky][x] = sum_c ex_c(x) G_c[ky]: one table
+    for a twist serves every rise; the half-plane spectrum it leads to is the oracle's, up to the Gaussian
+    tails below 2^-24 that the kernels drop."""
+    n, apix, twist = 64, 2.0, 29.0
+    d, br = 0.4 * n * apix, 2 * apix
+    rises = (9.0, 10.0, 11.5)
+    imax_t = int(np.ceil(n * apix / min(rises)))
+    tab, rpx, sigma2 = KM.run_table(n, apix, twist, csym, rot, d, br, imax_t)
+    for rise in rises:
+        H = KM.first_pass_from_table(tab, rpx, sigma2, n, apix, rise, imax_t)
+        F = KM.second_pass(H)
+        img = O.simulate_helical_projection(1, twist, rise, csym, d, br, 0, 0, n, n, apix, rot=rot)
+        ref = np.fft.fft2(img)[: n // 2 + 1]
+        assert np.abs(F - ref).max() < 2e-5 * np.abs(ref).max()
