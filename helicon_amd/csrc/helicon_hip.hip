@@ -15,7 +15,7 @@
 //   runs of candidates sharing (twist, csym, rot), no tilt/psi — the driver's twist-major grid:
 //     k_run_table     column transforms of every subunit's footprint, once per run.
 //     k_first_pass_table + k_second_pass ("run tables"): H as a short weighted sum of table rows.
-//     k_fused_pass ("fused", the default): one ky block of up to 16 candidates per workgroup, H built
+//     k_fused_pass ("fused", the default): one ky block of up to 64 candidates per workgroup, H built
 //                     in LDS from the table slice and the candidate's column factors, row FFT and
 //                     moments in place; no intermediate in HBM.
 //   finalize          Pearson coefficient from the moments [analysis.py:793-799]: grid layer 0 of the
@@ -65,7 +65,7 @@
 #define HH_KT_KYW 128      // run-table first pass: ky rows per workgroup
 #endif
 #ifndef HH_KF_CPW
-#define HH_KF_CPW 16       // fused pass: candidates per workgroup
+#define HH_KF_CPW 64       // fused pass: candidates per workgroup (of one run) in large launches; 16 in small ones
 #endif
 #ifndef HH_FUSED_BATCH
 #define HH_FUSED_BATCH 32768  // fused pass: candidates per launch (whole runs); 1.3 GB of column factors + moments at N = 512
@@ -1388,7 +1388,8 @@ struct FusedArgs {
   int n_kb;
   int batch;              // candidates in this launch
   int run_len;            // candidates per run inside this batch
-  int groups_per_run;     // workgroup layers per run: ceil(run_len / CPW)
+  int cpw;                // candidates per workgroup (of one run)
+  int groups_per_run;     // workgroup layers per run: ceil(run_len / cpw)
   int cap;                // table rows reserved per run
   int rows_lds;           // table rows staged per ky (>= every run's row count, >= kg)
   int kg;                 // table rows per group of four columns
@@ -1402,7 +1403,6 @@ template <int N>
 struct KF {
   static constexpr int T = N / 8;
   static constexpr int THREADS = N;
-  static constexpr int CPW = HH_KF_CPW;            // candidates per workgroup
   static constexpr int BROW = N + 4;               // complex slots per panel row (+32 B against bank conflicts)
   static constexpr size_t LDS_BUF = (size_t)8 * BROW * sizeof(float2);
   static size_t lds(int rows_lds, int kg) {
@@ -1438,9 +1438,9 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   const int kb = a.kb_list ? a.kb_list[blockIdx.x] : (int)blockIdx.x;
   const int row = kb * 8 + gi;
   const int run = gy / a.groups_per_run;
-  const int off = (gy % a.groups_per_run) * K::CPW;
+  const int off = (gy % a.groups_per_run) * a.cpw;
   const int cfirst = run * a.run_len + off;
-  const int nc = min(K::CPW, min(a.run_len - off, a.batch - cfirst));
+  const int nc = min(a.cpw, min(a.run_len - off, a.batch - cfirst));
   if (nc <= 0) return;
 
   float2 tw[TwN<N>::total];
@@ -2619,7 +2619,14 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       fu.n_kb = c->n_kb;
       fu.batch = bt.nb;
       fu.run_len = bt.run_len;
-      fu.groups_per_run = (fu.run_len + HH_KF_CPW - 1) / HH_KF_CPW;
+      // candidates per workgroup: many amortise the slice and weight loads (C2: +3 % at 64 over 16), but a launch
+      // needs a few rounds of workgroups to fill the chip evenly
+      {
+        const int64_t runs_b = (bt.nb + fu.run_len - 1) / fu.run_len;
+        fu.cpw = HH_KF_CPW;
+        while (fu.cpw > 16 && runs_b * ((fu.run_len + fu.cpw - 1) / fu.cpw) * c->n_kb < 4096) fu.cpw /= 2;
+      }
+      fu.groups_per_run = (fu.run_len + fu.cpw - 1) / fu.cpw;
       fu.cap = plan.rows;
       fu.rows_lds = plan.rows_f;
       fu.kg = plan.kg;
