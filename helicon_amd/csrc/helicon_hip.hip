@@ -2022,7 +2022,7 @@ struct hh_ctx {
   float2* d_inter = nullptr;     // [max_batch][N/2][N]
   double* d_partials = nullptr;  // [2][max_batch][NPART][3], zero where the mask skips a ky block; the halves alternate
                                  // between batches (the fused pass scores batch i-1 while it writes batch i)
-  double* d_psum = nullptr;      // S > 1: [max_batch][3] summed partials
+  double* d_psum = nullptr;      // S > 1: [b_pad][3] summed partials
   double* d_params = nullptr;    // staging for hh_sweep
   float* d_scores = nullptr;
   int64_t cap_params = 0;
@@ -2862,7 +2862,6 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMemset(c->d_partials, 0, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
   c->cap_partials = max_batch;
-  HH_CREATE_HIP(hipMalloc(&c->d_psum, (size_t)max_batch * 3 * sizeof(double)));
   HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
 
   std::vector<float2> tw((size_t)n);
@@ -3066,13 +3065,14 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     }
     c->ref[s] = RefConsts{sw, swec, var_e};
   }
-  for (void* p : {(void*)c->d_w2, (void*)c->d_wec, (void*)c->d_q, (void*)c->d_cpart, (void*)c->d_ref})
+  for (void* p : {(void*)c->d_w2, (void*)c->d_wec, (void*)c->d_q, (void*)c->d_cpart, (void*)c->d_ref, (void*)c->d_psum})
     if (p) HH_HIP(c, hipFree(p));
   c->d_w2 = nullptr;
   c->d_wec = nullptr;
   c->d_q = nullptr;
   c->d_cpart = nullptr;
   c->d_ref = nullptr;
+  c->d_psum = nullptr;
   HH_HIP(c, hipMalloc(&c->d_w2, w2.size() * sizeof(float2)));
   HH_HIP(c, hipMemcpyAsync(c->d_w2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
   if (multi) {
@@ -3080,6 +3080,7 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     HH_HIP(c, hipMalloc(&c->d_q, (size_t)b_pad * nh * sizeof(float)));
     HH_HIP(c, hipMalloc(&c->d_cpart, (size_t)(n / 2 + 1) * b_pad * s_pad * sizeof(float)));
     HH_HIP(c, hipMalloc(&c->d_ref, (size_t)n_segments * sizeof(RefConsts)));
+    HH_HIP(c, hipMalloc(&c->d_psum, (size_t)b_pad * 3 * sizeof(double)));  // one triple per candidate of a batch
     HH_HIP(c, hipMemcpyAsync(c->d_wec, wecm.data(), wecm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HH_HIP(c, hipMemcpyAsync(c->d_ref, c->ref.data(), (size_t)n_segments * sizeof(RefConsts), hipMemcpyHostToDevice,
                              c->stream));

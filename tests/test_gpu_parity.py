@@ -772,3 +772,20 @@ def test_c2_full_grid_fused_sweep_spot_checked_against_oracle():
     ref = O.sweep_cpu(img, grid.params[pick, :3], O.radial_band_mask(n, n), apix=apix, helical_diameter=d, ball_radius=br)
     np.testing.assert_allclose(fused[pick], ref, rtol=0, atol=SCORE_TOL)
     assert np.abs(fused[pick] - ref).max() < 2e-5
+
+
+def test_several_segments_in_batches_larger_than_max_batch():
+    """Several segments through the shared-twist pipelines use launches of up to 1024 candidates whatever
+    max_batch is (regression: a per-candidate buffer was sized by max_batch)."""
+    n, apix = 64, 2.0
+    img, d, br = _noisy_helix(n, apix, 29.0, 10.0, 1, seed=5)
+    from helicon_amd.grid import build_grid
+    grid = build_grid(np.array([27.0, 28.0, 29.0, 30.5]), 10.0 + 0.02 * np.arange(-35, 35), (2,), tube_length=n * apix)
+    imgs = np.stack([img, img[::-1].copy(), img[:, ::-1].copy()])
+    for mb in (16, 50):
+        with H.SweepEngine(n, max_batch=mb) as eng:
+            eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+            eng.set_reference(imgs)
+            tab, gen, used = _both_first_passes(eng, grid.params)
+        assert used == "fused" and tab.shape == (3, 280)
+        np.testing.assert_allclose(tab, gen, rtol=0, atol=2e-5)
