@@ -246,8 +246,9 @@ def roofline(prof, n, b_alg, pipeline):
     `transform` and `run_tables` pipelines do exactly that (`kernels` gives each kernel's own half
     and its measured traffic).  The `fused` pipeline keeps the intermediate in LDS, so it moves
     almost none of B_alg (`traffic` << `achieved` x time) and the same formula can exceed 1.0: the
-    section-8d roofline does not bound it.  What bounds it is vector issue; `valu` prices the
-    section-8d FLOP count (5 N^2 log2 N per candidate) against the fp32 vector peak.
+    section-8d roofline does not bound it.  The kernel is compute-side limited (vector and LDS pipes each
+    about 60 % busy, waves waiting on LDS round trips at 4 waves per SIMD: DESIGN.md section 4); `valu`
+    prices the section-8d FLOP count (5 N^2 log2 N per candidate) against the fp32 vector peak.
     `traffic` = measured bytes per launch (bytes per candidate from the calibrated FETCH_SIZE /
     WRITE_SIZE passes in profiles/traffic.json x the candidates of an average sampled launch)."""
     half = 8 * n * (n // 2 + 1)
@@ -300,7 +301,7 @@ def roofline(prof, n, b_alg, pipeline):
         flops = 5.0 * n * n * np.log2(n)  # r2c 2-D FFT, 11.8 MFLOP at 512
         tf = flops * cand / (device_ms * 1e-3) / 1e12
         out["note"] = ("fused pass: the half spectrum never goes to HBM, so B_alg is not moved and frac can exceed 1; "
-                       "the kernel is vector-issue bound (see valu)")
+                       "the kernel is limited on the compute side (vector + LDS pipes, see valu and DESIGN.md section 4)")
         out["valu"] = {"bound": "fp32 vector", "alg_flop_per_candidate": flops, "achieved": tf,
                        "peak": F32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf / (F32_VECTOR_PEAK / 1e12)}
     return out

@@ -300,8 +300,8 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
 
 // In: v[m] = x[t + m*T].  Out: v[m] = X[t + m*T], X = forward DFT (exp(-2 pi i nk/N)).
 // All T lanes of the transform must call it (group_sync inside; block-wide for T > 64).
-// SWZ1: xor-swizzle the first exchange (worth it where LDS, not vector issue, is the tighter resource:
-// the second pass and the fused pass; the raster + column-transform kernel is vector-issue bound).
+// SWZ1: xor-swizzle the first exchange (worth it where LDS time matters more than nine extra vector
+// instructions: the second pass and the fused pass; not in the raster + column-transform kernel).
 template <int N, bool SWZ1 = false, typename TW>
 __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   using P = Plan<N>;
