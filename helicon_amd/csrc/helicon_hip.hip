@@ -2025,7 +2025,7 @@ struct hh_ctx {
   double* d_psum = nullptr;      // S > 1: [b_pad][3] summed partials
   double* d_params = nullptr;    // staging for hh_sweep
   float* d_scores = nullptr;
-  int64_t cap_params = 0;
+  int64_t cap_params = 0, cap_scores = 0;
   double* d_units = nullptr;
   float2* d_w2 = nullptr;        // [N/2+1][N/8][8] (lane-major within a row); with S > 1 only w is used
   float* d_wec = nullptr;        // S > 1: [Sp][K] w (E_s - Ebar_s), natural bin order, Sp = S rounded up to 64
@@ -3137,21 +3137,21 @@ int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
   HH_HIP(c, hipSetDevice(c->device));
   if (g > c->cap_params) {
     if (c->d_params) HH_HIP(c, hipFree(c->d_params));
-    if (c->d_scores) HH_HIP(c, hipFree(c->d_scores));
     c->d_params = nullptr;
-    c->d_scores = nullptr;
     c->cap_params = 0;
     HH_HIP(c, hipMalloc(&c->d_params, (size_t)g * 4 * sizeof(double)));
-    HH_HIP(c, hipMalloc(&c->d_scores, (size_t)g * sizeof(float) * 1));
     c->cap_params = g;
   }
-  // scores for all segments: S x G
-  float* d_sc = nullptr;
-  if (c->n_segments > 1) {
-    HH_HIP(c, hipMalloc(&d_sc, (size_t)g * c->n_segments * sizeof(float)));
-  } else {
-    d_sc = c->d_scores;
+  // staging for the scores of all segments (S x G); kept between calls
+  const int64_t need_scores = g * c->n_segments;
+  if (need_scores > c->cap_scores) {
+    if (c->d_scores) HH_HIP(c, hipFree(c->d_scores));
+    c->d_scores = nullptr;
+    c->cap_scores = 0;
+    HH_HIP(c, hipMalloc(&c->d_scores, (size_t)need_scores * sizeof(float)));
+    c->cap_scores = need_scores;
   }
+  float* const d_sc = c->d_scores;
   hipError_t e = hipMemcpyAsync(c->d_params, params, (size_t)g * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     rc = sweep_on_device(c, c->d_params, g, d_sc, params);
@@ -3160,7 +3160,6 @@ int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
   }
-  if (c->n_segments > 1) (void)hipFree(d_sc);
   if (rc) return rc;
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_sweep: ") + hipGetErrorString(e));
   return HH_OK;
