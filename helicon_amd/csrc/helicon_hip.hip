@@ -1399,6 +1399,9 @@ struct FusedArgs {
   FactorArgs next;
 };
 
+typedef __attribute__((address_space(1))) const void* gptr_t;  // operands of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int N>
 struct KF {
   static constexpr int T = N / 8;
@@ -1490,17 +1493,23 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     const int cur = cc & 1;
     const float* const egc = eg + (size_t)cur * a.kg * N;
     const int* const cgc = cgs + cur * (N / 4);
-    // next candidate's column factors: the loads fly under this candidate's panel build
-    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0, nx3 = nx0;
-    int ncg = 0;
+    // next candidate's column factors: copied global -> LDS by the load unit itself (no registers, no ds_write
+    // pass) into the other factor buffer, which nobody reads before the barrier at the end of this iteration;
+    // that barrier also waits for the copies (they count on vmcnt).  One wave-instruction moves 64 x 16 B to a
+    // wave-uniform LDS base + lane x 16.
     const bool more = cc + 1 < nc && !(HH_ABLATE & 4096);
     if (more) {
-      const float4* const src = reinterpret_cast<const float4*>(a.eg + (b + 1) * a.kg * N);
-      nx0 = src[min(tid, n_e4 - 1)];
-      nx1 = src[min(tid + K::THREADS, n_e4 - 1)];
-      nx2 = src[min(tid + 2 * K::THREADS, n_e4 - 1)];
-      nx3 = src[min(tid + 3 * K::THREADS, n_e4 - 1)];
-      ncg = a.cgs[(b + 1) * (N / 4) + min(tid, N / 4 - 1)];
+      const char* const gsrc = reinterpret_cast<const char*>(a.eg + (b + 1) * a.kg * N);
+      char* const ldst = reinterpret_cast<char*>(eg + (size_t)(cur ^ 1) * a.kg * N);
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int p0 = wave * 64; p0 < n_e4; p0 += K::THREADS)  // (a workgroup narrower than a wavefront: wave = 0)
+        if (p0 + lane < n_e4)
+          __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)(p0 + lane) * 16),
+                                           (lptr_t)(ldst + (size_t)p0 * 16), 16, 0, 0);
+      if (wave == 0 && lane < N / 16)  // the groups' first table rows: N/4 ints
+        __builtin_amdgcn_global_load_lds(
+            (gptr_t)(reinterpret_cast<const char*>(a.cgs + (b + 1) * (N / 4)) + lane * 16),
+            (lptr_t)(reinterpret_cast<char*>(cgs + (cur ^ 1) * (N / 4))), 16, 0, 0);
     }
     // ---- this group's row of H, built by the group itself into its own exchange buffer (no
     // workgroup barrier): a lane takes four consecutive columns at a time
@@ -1531,14 +1540,6 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
     if constexpr (T > 64) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
-    if (more) {  // into the other factor buffer: nobody reads it before the barrier at the end of this iteration
-      float4* const dst = reinterpret_cast<float4*>(eg + (size_t)(cur ^ 1) * a.kg * N);
-      if (tid < n_e4) dst[tid] = nx0;
-      if (tid + K::THREADS < n_e4) dst[tid + K::THREADS] = nx1;
-      if (tid + 2 * K::THREADS < n_e4) dst[tid + 2 * K::THREADS] = nx2;
-      if (tid + 3 * K::THREADS < n_e4) dst[tid + 3 * K::THREADS] = nx3;
-      if (tid < N / 4) cgs[(cur ^ 1) * (N / 4) + tid] = ncg;
-    }
     if (!(HH_ABLATE & 16)) fft_lanes<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
 
     bool scored = false;
