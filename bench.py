@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: helical-parameter candidates/s on a 512x512 image over a 100k-point
-(twist, rise) grid (BASELINE.json configs[1] = SURVEY.md section 8d "C2"), one MI355X per rank.
+(twist, rise) grid (BASELINE.json configs[1] = SURVEY.md section 8d "C2").
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the sweep over this rank's 100k-candidate shard with the parameters and the
-experimental spectrum already resident in HBM, followed (N > 1) by the RCCL all-gather of the
-scores.  Weak scaling: every rank owns one full 400 x 250 grid at Csym = 1 (rank r sweeps it at
-azimuthal phase rot = 7.5 r degrees, so all ranks do identical work): 100k x N candidates per step.
+A step = one pass of the sweep over the C2 grid with the candidate list and the experimental spectrum
+already resident in HBM: every rank sweeps its contiguous shard of the ONE 400 x 250 grid (whole twists per
+rank, helicon_amd.distributed.ShardedSweep), the scores are all-gathered (RCCL; N > 1 only) and every rank
+takes the arg-max on the device.  That is the north_star's experiment, so N > 1 is STRONG scaling by default;
+`--scaling weak` gives every rank its own full grid instead.  `python bench.py --gpus N` without a launcher
+starts its own N rank processes (children, before this process touches the GPU) and relays rank 0's line.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -23,7 +27,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md "HBM3E peak BW")
+HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md "HBM3E peak BW")
+F32_VECTOR_PEAK = 157.3e12   # FLOP/s, MI355X fp32 vector (= fp32 MFMA) peak, MI355X_MICROARCH.md
 
 
 def c2_workload(n=512):
@@ -41,7 +46,7 @@ def baseline_metric():
     try:
         return json.loads((ROOT / "BASELINE.json").read_text())["metric"]
     except Exception:
-        return "helical-param candidates/sec (512\u00b2 image, 100k-pt grid) + HBM roofline %"
+        return "helical-param candidates/sec (512² image, 100k-pt grid) + HBM roofline %"
 
 
 def usable_cores():
@@ -70,14 +75,42 @@ def cpu_baseline_leg(w, sample_per_core=48):
                             cores=cores, n_candidates=sample_per_core * cores)
 
 
-def main():
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as children of this process (which has
+    not imported torch, let alone touched the GPU) and exit with their status.  Never an exec."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_factory(spec):
+    """`module:callable` -> the engine factory (default: helicon_amd.SweepEngine).  Tests rehearse the launch and
+    collective plumbing on CPU with a stand-in engine; the product path is the default."""
+    import importlib
+
+    mod, _, name = spec.partition(":")
+    return getattr(importlib.import_module(mod), name)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=512, help="image side (default: the C2 workload)")
+    ap.add_argument("--side", dest="n", type=int, default=512, help="image side (default: the C2 workload)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the one C2 grid sharded over the ranks (default, the north_star's experiment); "
+                         "weak = a full grid per rank (rot = 7.5 deg x rank)")
+    ap.add_argument("--csyms", type=int, nargs="+", default=[1], help="Csym values of the grid (1 2 3 4 5 6 = C3)")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the run-tables / transform / C3 legs at N = 1")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--profile-period", type=int, default=16,
                     help="HIP events around the launches of every k-th batch of the timed sweeps (1 = all)")
@@ -87,13 +120,55 @@ def main():
     ap.add_argument("--first-pass", default="auto", choices=["auto", "tables", "transform"],
                     help="auto: the library's choice (fused pass on twist-major grids); tables: run tables + "
                          "second pass through the HBM intermediate; transform: raster + two transforms per candidate")
-    args = ap.parse_args()
+    ap.add_argument("--engine", default="helicon_amd:SweepEngine", help=argparse.SUPPRESS)
+    ap.add_argument("--dump-scores", default=None, help="rank 0 writes the gathered scores [S, G] of the last step (.npy)")
+    return ap.parse_args(argv)
+
+
+class Timed:
+    """W warm-up steps, then exactly K steps bracketed by barrier + device synchronise; max over ranks."""
+
+    def __init__(self, torch, dist, dev, world, on_gpu, backend):
+        self.torch, self.dist, self.dev, self.world, self.on_gpu, self.backend = torch, dist, dev, world, on_gpu, backend
+
+    def fence(self):
+        if self.on_gpu:
+            self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+            if self.on_gpu:
+                self.torch.cuda.synchronize(self.dev)
+
+    def run(self, step, warmup, steps, before_timed=None):
+        self.fence()
+        for _ in range(warmup):
+            step()
+        self.fence()
+        if before_timed:
+            before_timed()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64,
+                                  device=self.dev if (self.backend == "nccl" and self.on_gpu) else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     w = c2_workload(args.n)
 
@@ -106,21 +181,25 @@ def main():
     import torch.distributed as dist
 
     import helicon_amd as H
-    from helicon_amd.distributed import gather_scores
+    from helicon_amd.distributed import ShardedSweep
 
+    Engine = load_factory(args.engine)
+    on_gpu = args.engine == "helicon_amd:SweepEngine"
     if args.same_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if args.backend == "nccl" and on_gpu:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    timed = Timed(torch, dist, dev, world, on_gpu, args.backend)
 
     n = w["n"]
-    eng = H.SweepEngine(n, device=local_rank, max_batch=args.max_batch)
+    eng = Engine(n, device=local_rank, max_batch=args.max_batch)
     eng.set_geometry(apix=w["apix"], helical_diameter=w["helical_diameter"], ball_radius=w["ball_radius"])
     tw0, rs0, cs0 = w["truth"]
     clean = eng.simulate(tw0, rs0, cs0)
@@ -128,73 +207,75 @@ def main():
     image = (clean + noise).astype(np.float32)
     eng.set_reference(image, H.radial_band_mask(n, n), log=True)
 
-    grid = w["build_grid"](w["twists"], w["rises"], (1,), tube_length=n * w["apix"], rot=7.5 * rank)
-    assert grid.valid.all()
-    g_local = len(grid)
-    stream = torch.cuda.current_stream(dev)
-    eng.set_stream(stream.cuda_stream)
-    d_params = torch.from_numpy(grid.params).to(dev)
-    d_scores = torch.empty((1, g_local), dtype=torch.float32, device=dev)
-    h_params = grid.params if args.first_pass != "transform" else None  # the host mirror lets the library see the runs
-    eng.set_table_path({"auto": 2, "tables": 1, "transform": 0}[args.first_pass])
+    n_rises = len(w["rises"])
+    strong = args.scaling == "strong" or world == 1
 
-    def step():
-        eng.sweep_device(d_params.data_ptr(), g_local, d_scores.data_ptr(), host_params=h_params)
-        if world > 1:
-            local = d_scores if args.backend == "nccl" else d_scores.cpu()
-            return gather_scores(local, g_local * world, g_local)
-        return d_scores
+    def make_sweep(csyms, first_pass="auto"):
+        """(ShardedSweep, the whole candidate list): the list sharded over the ranks (strong) or a full grid per
+        rank (weak; the list is then the concatenation of the ranks' grids)."""
+        def grid_of(r):
+            g = w["build_grid"](w["twists"], w["rises"], tuple(csyms), tube_length=n * w["apix"], rot=7.5 * r)
+            assert g.valid.all()
+            return g.params
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        eng.set_table_path({"auto": 2, "tables": 1, "transform": 0}[first_pass])
+        if strong:
+            full = grid_of(0)
+            sh = ShardedSweep(eng, full, align=n_rises, device=dev)
+        else:
+            full = np.concatenate([grid_of(r) for r in range(world)])
+            sh = ShardedSweep(eng, full, align=len(full) // world, device=dev)
+        if first_pass == "transform":
+            sh.h_params = None  # no host mirror: the library cannot see the runs
+        return sh, full
+
+    sh, params_all = make_sweep(args.csyms, args.first_pass)
+    g_total = sh.n_total
 
     # set-up: the library sizes its device buffers (run tables, column factors, moments) on the first sweep of
     # a given list, like an allocation; do that before the W warm-up steps so that W = 0 still times steady state
-    step()
-    fence()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if not args.no_profile:
-        # the fused pipeline runs a sweep in a handful of long launches: time all of them (events around a few
-        # launches cost nothing), so the averages are over the same launches rocprofv3 sees
-        eng.profile(1 if eng.last_first_pass == "fused" else args.profile_period)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_get() if not args.no_profile else None
+    sh.step()
+
+    def start_profile():
+        if not args.no_profile and on_gpu:
+            # the fused pipeline runs a sweep in a handful of long launches: time all of them (events around a few
+            # launches cost nothing), so the averages are over the same launches rocprofv3 sees
+            eng.profile(1 if eng.last_first_pass == "fused" else args.profile_period)
+
+    elapsed = timed.run(sh.step, args.warmup, args.steps, before_timed=start_profile)
+    prof = eng.profile_get() if (not args.no_profile and on_gpu) else None
     if prof is not None:
-        prof["candidates_total"] = g_local * args.steps
-    eng.profile(0)
+        prof["candidates_total"] = sh.n_local * args.steps
+        eng.profile(0)
+    pipeline = eng.last_first_pass
+
+    # correctness of what was timed: the arg-max of the gathered scores must be the synthetic truth
+    best = int(sh.best_index()[0])
+    scores = sh.scores()
+    assert best == int(np.argmax(np.where(np.isnan(scores[0]), -np.inf, scores[0]))), "device arg-max != host arg-max"
+    best_pair = (round(float(params_all[best, 0]), 6), round(float(params_all[best, 1]), 6), int(params_all[best, 2]))
+    if rank == 0 and args.dump_scores:
+        np.save(args.dump_scores, scores)
+
+    # where a step's time goes on this rank (untimed extra steps, device events between the phases)
+    phases = phase_times(torch, sh, dev, on_gpu) if on_gpu else None
 
     # the host-pointer API (params H2D + scores D2H inside the call), reported beside `value`
     host_api = None
-    if world == 1:
-        eng.sweep(grid.params[:1024])
+    extra = {}
+    if world == 1 and on_gpu:
+        eng.set_stream(None)
+        eng.sweep(params_all[:1024])
         th = time.perf_counter()
-        eng.sweep(grid.params)
-        host_api = g_local / (time.perf_counter() - th)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # correctness of what was timed: rank 0's grid (rot = 0) must have its arg-max at the truth
-    scores = full.cpu().numpy().reshape(world, g_local)
-    best = int(np.argmax(scores[0]))
-    _, bt, br_ = np.unravel_index(best, (1, len(w["twists"]), len(w["rises"])))
-    best_pair = (round(float(grid.params[best, 0]), 6), round(float(grid.params[best, 1]), 6))
+        eng.sweep(params_all)
+        host_api = g_total / (time.perf_counter() - th)
+        if not args.no_extra_legs and args.first_pass == "auto" and args.csyms == [1]:
+            extra = extra_legs(args, eng, timed, make_sweep, n)
 
     if rank == 0:
-        total = g_local * world * args.steps
+        total = g_total * args.steps
         value = total / elapsed
-        b_alg = eng.algorithmic_bytes()
+        b_alg = eng.algorithmic_bytes() if on_gpu else 0
         out = {
             "metric": baseline_metric(),
             "value": value,
@@ -204,32 +285,87 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), "
-                            f"400x250 (twist, rise) grid per GPU, Csym = 1, rot = 7.5 deg x rank, radial-band mask, log1p|F|",
-                "image": n, "grid_per_gpu": g_local, "candidates_per_step": g_local * world,
-                "batch": eng.max_batch, "first_pass": eng.last_first_pass, "parallelism": f"grid-shard x{world} + all-gather(scores)",
+                "workload": (f"C2: {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), ONE 400x250 "
+                             f"(twist, rise) grid x Csym {args.csyms} "
+                             + ("sharded over the ranks in whole twists" if strong else "per GPU (rot = 7.5 deg x rank)")
+                             + ", radial-band mask, log1p|F|"),
+                "image": n, "candidates_per_step": g_total, "candidates_per_rank": sh.per,
+                "batch": getattr(eng, "max_batch", 0), "first_pass": pipeline,
+                "parallelism": f"grid-shard x{world} + all-gather(scores) + device arg-max",
             },
-            "argmax": {"twist": best_pair[0], "rise": best_pair[1], "is_truth": best_pair == (tw0, rs0)},
-            "hbm_roofline_frac_wall": value / world * b_alg / HBM_PEAK,
+            "argmax": {"index": best, "twist_rise_csym": best_pair,
+                       "is_truth": best_pair == (tw0, rs0, cs0)},
         }
+        if phases is not None:
+            out["step_phases_rank0"] = phases
         if host_api is not None:
             out["host_api_value"] = host_api  # hh_sweep with host buffers, PCIe-inclusive
         if prof is not None and prof["n_second_pass"] > 0:
-            out["roofline"] = roofline(prof, n, b_alg, eng.last_first_pass)
+            out["roofline"] = roofline(prof, n, b_alg, pipeline)
+        if extra:
+            out["pipelines"] = extra
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-F32_VECTOR_PEAK = 157.3e12  # FLOP/s, MI355X fp32 vector (= fp32 MFMA) peak, MI355X_MICROARCH.md
+def phase_times(torch, sh, dev, on_gpu, reps=5):
+    """ms per step of the sweep kernels, the all-gather and the arg-max on this rank (device events on the
+    stream all three are queued on), and the host time to queue one step (`ms_fixed_host`, which the GPU hides
+    as long as it is shorter than the device time)."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    torch.cuda.synchronize(dev)
+    host = 0.0
+    for e in ev:
+        t0 = time.perf_counter()
+        e[0].record()
+        sh.sweep()
+        e[1].record()
+        sh.gather()
+        e[2].record()
+        sh.argmax()
+        e[3].record()
+        host += time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    ms = np.array([[a.elapsed_time(b) for a, b in zip(e[:-1], e[1:])] for e in ev]).mean(axis=0)
+    return {"ms_sweep": float(ms[0]), "ms_allgather": float(ms[1]), "ms_argmax": float(ms[2]),
+            "ms_fixed_host": 1e3 * host / reps}
+
+
+def extra_legs(args, eng, timed, make_sweep, n):
+    """N = 1 only: the two pipelines that DO move the intermediate through HBM, and C3 (the 600k list), each
+    timed like the headline (fewer steps), so the driver's own run carries their numbers."""
+    out = {}
+    b_alg = eng.algorithmic_bytes()
+    for name, fp, csyms, steps in (("run_tables", "tables", [1], 3), ("transform", "transform", [1], 3),
+                                   ("c3_csym_1_to_6", "auto", [1, 2, 3, 4, 5, 6], 2)):
+        sh, _ = make_sweep(csyms, fp)
+        sh.step()
+
+        def start():
+            eng.profile(1 if eng.last_first_pass == "fused" else args.profile_period)
+
+        el = timed.run(sh.step, 1, steps, before_timed=start)
+        prof = eng.profile_get()
+        prof["candidates_total"] = sh.n_local * steps
+        eng.profile(0)
+        leg = {"value": sh.n_total * steps / el, "unit": "candidates/s", "steps": steps, "candidates_per_step": sh.n_total,
+               "first_pass": eng.last_first_pass, "argmax_index": int(sh.best_index()[0])}
+        if prof["n_second_pass"] > 0:
+            leg["roofline"] = roofline(prof, n, b_alg, eng.last_first_pass)
+        out[name] = leg
+        del sh
+    eng.set_table_path(2)
+    return out
+
 
 PIPELINES = {
     # pipeline -> ((JSON name, traffic.json key, what it moves per candidate), ...) for profile slots 0 and 1
@@ -242,29 +378,34 @@ PIPELINES = {
 }
 
 
+def traffic_table(n):
+    """Measured bytes per candidate per kernel (profiles/traffic.json, written from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes by tools/traffic_parse.py) and a label saying where they come from."""
+    tfile = ROOT / "profiles" / "traffic.json"
+    try:
+        doc = json.loads(tfile.read_text())
+        return doc.get(f"n{n}", {}), f"profiles/traffic.json ({doc.get('source', 'rocprofv3 --pmc passes, not this run')})"
+    except Exception:
+        return {}, None
+
+
 def roofline(prof, n, b_alg, pipeline):
-    """achieved = B_alg(N) bytes per candidate x candidates / device time of the
-    launches that process them, all measured with HIP events on the sweep's stream over sampled
-    batches of the timed region, against the 8 TB/s HBM peak.  B_alg = 4 N^2 + 16 N (N/2+1) prices a
-    pipeline that writes the column-transformed half spectrum to HBM and reads it back.  The
-    `transform` and `run_tables` pipelines do exactly that (`kernels` gives each kernel's own half
-    and its measured traffic).  The `fused` pipeline keeps the intermediate in LDS, so it moves
-    almost none of B_alg (`traffic` << `achieved` x time) and the same formula can exceed 1.0: the
-    section-8d roofline does not bound it.  The kernel is compute-side limited (vector and LDS pipes each
-    about 60 % busy, waves waiting on LDS round trips at 4 waves per SIMD: DESIGN.md section 4); `valu`
-    prices the section-8d FLOP count (5 N^2 log2 N per candidate) against the fp32 vector peak.
-    `traffic` = measured bytes per launch (bytes per candidate from the calibrated FETCH_SIZE /
-    WRITE_SIZE passes in profiles/traffic.json x the candidates of an average sampled launch)."""
+    """One object per timed pipeline; every `frac` in it is a fraction of a physical peak (<= 1).
+
+    * two-pass pipelines (`transform`, `run_tables`): bound = HBM.  The kernels write the column-transformed half
+      spectrum (8 N (N/2+1) bytes per candidate) and read it back; the simulated image is never stored, so the bytes
+      moved are 16 N (N/2+1), not SURVEY section 8d's B_alg (which adds 4 N^2 for "reading the image").  `achieved` =
+      moved bytes x candidates / device time of the sampled launches (HIP events on the sweep's stream).
+    * `fused`: the half spectrum stays in LDS, HBM sees ~5 % of those bytes, so HBM does not bound the kernel; the
+      bound that applies is the fp32 vector pipe.  `achieved` = section 8d's FLOP count (5 N^2 log2 N per candidate)
+      x candidates / device time against the 157.3 TFLOP/s fp32 vector peak.  The section-8d HBM model is kept as
+      `hbm_model` (a two-pass-equivalent rate, explicitly not a bound) and the measured traffic as `hbm_measured`.
+    `traffic` = measured HBM-side bytes per launch of the dominant kernel(s), from `traffic_source` (a static file of
+    earlier counter passes — counters cannot be collected inside a timed run), or null."""
     half = 8 * n * (n // 2 + 1)
     slots = (("ms_first_pass", "n_first_pass"), ("ms_second_pass", "n_second_pass"))
     cand = prof["candidates"]
-    tfile = ROOT / "profiles" / "traffic.json"  # written from the rocprofv3 --pmc passes (see DESIGN.md)
-    measured = {}
-    if tfile.exists():
-        try:
-            measured = json.loads(tfile.read_text()).get(f"n{n}", {})
-        except Exception:
-            measured = {}
+    measured, source = traffic_table(n)
     kernels = {}
     main_launches = max(prof["n_first_pass"], prof["n_second_pass"])
     for (name, tkey, what), (ms_key, n_key) in zip(PIPELINES[pipeline], slots):
@@ -273,41 +414,56 @@ def roofline(prof, n, b_alg, pipeline):
             continue
         avg_us = 1e3 * prof[ms_key] / launches
         per_launch = cand / launches
-        per_cand = measured.get(tkey)  # measured bytes per candidate (profiles/traffic.json)
+        per_cand = measured.get(tkey)  # measured bytes per candidate
         entry = {"launches": launches, "avg_us": avg_us, "role": what,
                  "traffic": per_cand * per_launch if per_cand is not None else None}
         if pipeline != "fused":
             gbps = half * per_launch / (avg_us * 1e-6) / 1e9
-            entry.update({"candidates_per_launch": per_launch, "alg_bytes_per_candidate": half, "GBps": gbps,
+            entry.update({"candidates_per_launch": per_launch, "moved_bytes_per_candidate": half, "GBps": gbps,
                           "frac": gbps / (HBM_PEAK / 1e9)})
         elif name == "k_fused_pass":
-            entry["candidates_per_launch"] = cand / launches
+            entry["candidates_per_launch"] = per_launch
         kernels[name] = entry
     # run-table builds (one launch per sweep) are timed on every sweep but serve all of its batches:
     # scale them to the sampled share of the candidates
     share = cand / max(1, prof.get("candidates_total", cand))
     device_ms = prof["ms_first_pass"] + prof["ms_second_pass"] + prof["ms_finalize"] + prof["ms_centres"] * share
-    achieved = b_alg * cand / (device_ms * 1e-3) / 1e9
-    traffic = None
     dominant = [v for k, v in kernels.items() if k != "k_column_factors"]
+    traffic = None
     if dominant and all(v["traffic"] is not None for v in dominant):
         traffic = sum(v["traffic"] for v in dominant)
+    cand_per_s = cand / (device_ms * 1e-3)
     out = {
-        "bound": "hbm", "pipeline": pipeline,
+        "pipeline": pipeline,
         "kernel": " + ".join(k for k in kernels if k != "k_column_factors") + " (per batch)",
-        "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9),
-        "traffic": traffic, "alg_bytes_per_candidate": b_alg,
         "candidates_per_launch": cand / main_launches, "device_ms_sampled": device_ms,
         "run_table_ms_per_sweep": (prof["ms_centres"] / prof["n_centres"]) if prof["n_centres"] else None,
+        "traffic": traffic, "traffic_source": source,
         "kernels": kernels,
     }
+    model_gbps = b_alg * cand_per_s / 1e9
     if pipeline == "fused":
         flops = 5.0 * n * n * np.log2(n)  # r2c 2-D FFT, 11.8 MFLOP at 512
-        tf = flops * cand / (device_ms * 1e-3) / 1e12
-        out["note"] = ("fused pass: the half spectrum never goes to HBM, so B_alg is not moved and frac can exceed 1; "
-                       "the kernel is limited on the compute side (vector + LDS pipes, see valu and DESIGN.md section 4)")
-        out["valu"] = {"bound": "fp32 vector", "alg_flop_per_candidate": flops, "achieved": tf,
-                       "peak": F32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf / (F32_VECTOR_PEAK / 1e12)}
+        tf = flops * cand_per_s / 1e12
+        out.update({"bound": "fp32_vector", "achieved": tf, "peak": F32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": tf / (F32_VECTOR_PEAK / 1e12), "alg_flop_per_candidate": flops})
+        out["hbm_model"] = {"alg_bytes_per_candidate": b_alg, "two_pass_equivalent_GBps": model_gbps,
+                            "ratio_to_hbm_peak": model_gbps / (HBM_PEAK / 1e9),
+                            "note": "not a bound: section 8d's B_alg prices a half spectrum written to and read from HBM; "
+                                    "the fused pass keeps it in LDS, so these bytes are not moved"}
+        per_cand = measured.get("fused_pass")
+        if per_cand is not None:
+            gb = per_cand * cand_per_s / 1e9
+            out["hbm_measured"] = {"bytes_per_candidate": per_cand, "GBps": gb, "hbm_measured_frac": gb / (HBM_PEAK / 1e9),
+                                   "traffic_source": source}
+    else:
+        moved = 2 * half
+        gbps = moved * cand_per_s / 1e9
+        out.update({"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": gbps / (HBM_PEAK / 1e9), "moved_bytes_per_candidate": moved,
+                    "hbm_model": {"alg_bytes_per_candidate": b_alg, "GBps": model_gbps,
+                                  "ratio_to_hbm_peak": model_gbps / (HBM_PEAK / 1e9),
+                                  "note": "section 8d's B_alg counts 4 N^2 for reading an image that no pipeline stores"}})
     return out
 
 

@@ -65,11 +65,13 @@ EXPORTS = {
     "hh_sweep": (C.c_int, [_ctx, _f64p, C.c_int64, _f32p]),
     "hh_sweep_device": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
     "hh_sweep_device_mirrored": (C.c_int, [_ctx, C.c_void_p, _f64p, C.c_int64, C.c_void_p]),
+    "hh_sweep_device_strided": (C.c_int, [_ctx, C.c_void_p, _f64p, C.c_int64, C.c_void_p, C.c_int64]),
     "hh_set_table_path": (C.c_int, [_ctx, C.c_int]),
     "hh_last_first_pass": (C.c_int, [_ctx]),
     "hh_low_high_pass_filter": (C.c_int, [_ctx, _f32p, C.c_double, C.c_double, _f32p]),
     "hh_threshold_data": (C.c_int, [_ctx, _f32p, C.c_int64, C.c_int, C.c_double, _f32p]),
     "hh_argmax": (C.c_int, [_f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    "hh_argmax_device": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "hh_simulate": (C.c_int, [_ctx, _f64p, _f32p]),
     "hh_power_spectrum": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),
     "hh_cross_correlation": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f64p]),

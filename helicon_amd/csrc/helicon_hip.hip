@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/helicon_hip.h"
@@ -1494,9 +1495,9 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     const float* const egc = eg + (size_t)cur * a.kg * N;
     const int* const cgc = cgs + cur * (N / 4);
     // next candidate's column factors: copied global -> LDS by the load unit itself (no registers, no ds_write
-    // pass) into the other factor buffer, which nobody reads before the barrier at the end of this iteration;
-    // that barrier also waits for the copies (they count on vmcnt).  One wave-instruction moves 64 x 16 B to a
-    // wave-uniform LDS base + lane x 16.
+    // pass) into the other factor buffer, which nobody reads before the barrier at the end of this iteration
+    // (an explicit s_waitcnt vmcnt(0) ahead of that barrier retires the copies).  One wave-instruction moves
+    // 64 x 16 B to a wave-uniform LDS base + lane x 16.
     const bool more = cc + 1 < nc && !(HH_ABLATE & 4096);
     if (more) {
       const char* const gsrc = reinterpret_cast<const char*>(a.eg + (b + 1) * a.kg * N);
@@ -1616,6 +1617,9 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         o[2] = s3;
       }
     }
+    // The LDS-DMA copies of the next candidate's factors count on vmcnt only; neither the workgroup-scope fence nor
+    // s_barrier waits for them, so every wavefront retires its own copies before it arrives at the barrier.
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
   }
 }
@@ -1773,6 +1777,35 @@ __global__ void k_normalise(float* __restrict__ pwr, size_t n, const unsigned* _
   const float inv = 1.0f / (vmax - vmin);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     pwr[i] = (pwr[i] - vmin) * inv;
+}
+
+// arg-max of every row of scores[rows][n] (np.argmax: lowest index on ties; NaN never wins; all-NaN -> 0)
+__global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ scores, int64_t n, int64_t ld,
+                                                      int64_t* __restrict__ out) {
+  const float* const row = scores + (size_t)blockIdx.x * ld;
+  float bv = -INFINITY;
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = row[i];
+    if (v != v) continue;
+    if (bi < 0 || v > bv) { bv = v; bi = i; }  // ascending i per thread: the first maximum is kept
+  }
+  auto better = [](float v, int64_t i, float bv, int64_t bi) { return i >= 0 && (bi < 0 || v > bv || (v == bv && i < bi)); };
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_down(bv, off, 64);
+    const int64_t oi = __shfl_down(bi, off, 64);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  __shared__ float sv[16];
+  __shared__ int64_t si[16];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sv[w] = bv; si[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+      if (better(sv[k], si[k], bv, bi)) { bv = sv[k]; bi = si[k]; }
+    out[blockIdx.x] = bi < 0 ? 0 : bi;
+  }
 }
 
 template <typename T>
@@ -2033,6 +2066,9 @@ struct hh_ctx {
   float* d_q = nullptr;          // S > 1: [Bp][K] masked q of one batch, Bp = max_batch rounded up to 64
   float* d_cpart = nullptr;      // S > 1: [N/2+1][Bp][Sp] per-row covariance numerators
   RefConsts* d_ref = nullptr;    // S > 1: [S]
+  int64_t* d_argmax = nullptr;   // hh_argmax_device: one index per row
+  size_t cap_argmax = 0;
+  size_t cap_w2 = 0, cap_wec = 0, cap_q = 0, cap_cpart = 0, cap_ref = 0, cap_psum = 0, cap_kb = 0;  // bytes
   int* d_kb_list = nullptr;      // ky blocks (8 rows) the mask touches, ascending; block 0 always
   int n_kb = 0;
   float2* d_table = nullptr;     // shared-twist first pass: [runs per batch][rows][N/2] column-transform table
@@ -2058,6 +2094,10 @@ struct hh_ctx {
   int log_flag = 1;
   bool have_geom = false;
   DevGeom geom{};
+
+  // kernels whose dynamic-LDS limit has been raised on THIS context's device (function -> bytes granted); the
+  // attribute is per device, so it is tracked per context, never per process
+  std::vector<std::pair<const void*, int>> lds_attr;
 
   int profiling = 0;             // 0 off, k > 0: time every k-th batch of a sweep
   bool prof_now = false;         // the batch being enqueued is a sampled one
@@ -2104,6 +2144,21 @@ int npart_for(int n) {  // partial-moment slots per candidate (KB<N>::NPART)
   }                                                                 \
   return fail(c, HH_ERR_ARG, "unsupported image size")
 
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the device that is current when it is set; a context is
+// bound to one device, so it remembers what it has set (the caller has made c->device current).
+int ensure_lds_attr(hh_ctx* c, const void* fn, int bytes) {
+  for (auto& e : c->lds_attr)
+    if (e.first == fn) {
+      if (e.second >= bytes) return HH_OK;
+      HH_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      e.second = bytes;
+      return HH_OK;
+    }
+  HH_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  c->lds_attr.emplace_back(fn, bytes);
+  return HH_OK;
+}
+
 struct ProfScope {  // hipEvent pair around one launch when profiling is on
   hh_ctx* c;
   EventPair* ep = nullptr;
@@ -2126,12 +2181,7 @@ struct ProfScope {  // hipEvent pair around one launch when profiling is on
 template <int N, int MODE>
 int launch_first(hh_ctx* c, const FirstArgs& a, int batch) {
   using K = KA<N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_first_pass<N, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_lds_attr(c, reinterpret_cast<const void*>(&k_first_pass<N, MODE>), (int)K::LDS)) return rc;
   ProfScope ps(c, 0);
   hipLaunchKernelGGL((k_first_pass<N, MODE>), dim3(K::NQ, batch + (a.fin.n > 0 ? 1 : 0)), dim3(K::THREADS), K::LDS,
                      c->stream, a);
@@ -2142,12 +2192,7 @@ int launch_first(hh_ctx* c, const FirstArgs& a, int batch) {
 template <int N, int EPI, int LOG>
 int launch_second(hh_ctx* c, const SecondArgs& a, int batch) {
   using K = KB<N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_second_pass<N, EPI, LOG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
-    attr_done = true;
-  }
+  if (int rc = ensure_lds_attr(c, reinterpret_cast<const void*>(&k_second_pass<N, EPI, LOG>), (int)K::LDS)) return rc;
   ProfScope ps(c, 1);
   SecondArgs args = a;
   args.batch = batch;
@@ -2187,6 +2232,20 @@ template <int EPI>
 int dispatch_second(hh_ctx* c, const SecondArgs& a, int batch) {
   if (EPI != EPI_STORE && a.log_flag) return dispatch_second_n<EPI, 1>(c, a, batch);
   return dispatch_second_n<EPI, 0>(c, a, batch);
+}
+
+// grow-only device buffer
+int ensure_bytes(hh_ctx* c, void** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return HH_OK;
+  if (*p) HH_HIP(c, hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  if (hipMalloc(p, need) != hipSuccess) {
+    *p = nullptr;
+    return fail(c, HH_ERR_NOMEM, "device allocation of " + std::to_string(need) + " bytes failed");
+  }
+  *cap = need;
+  return HH_OK;
 }
 
 int ensure_img(hh_ctx* c, int64_t count) {
@@ -2429,12 +2488,7 @@ int launch_factors(hh_ctx* c, const FactorArgs& a, int batch) {
 template <int N, int EPI, int LOG>
 int launch_fused(hh_ctx* c, const FusedArgs& a, int layers) {
   using K = KF<N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_pass<N, EPI, LOG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  if (int rc = ensure_lds_attr(c, reinterpret_cast<const void*>(&k_fused_pass<N, EPI, LOG>), 160 * 1024)) return rc;
   ProfScope ps(c, 1);
   hipLaunchKernelGGL((k_fused_pass<N, EPI, LOG>), dim3(a.n_kb, a.factor_layers + layers + (a.fin.n > 0 ? 1 : 0)),
                      dim3(K::THREADS), K::lds(a.rows_lds, a.kg), c->stream, a);
@@ -2682,23 +2736,27 @@ int sweep_transform(hh_ctx* c, const double* d_params, int64_t g, float* d_score
   return HH_OK;
 }
 
-int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const double* h_params = nullptr) {
-  RunPlan plan = plan_runs(c, h_params, g);
+// ld: row stride of d_scores (segment s of candidate i goes to d_scores[s * ld + i]); the helpers below only use
+// their `g` argument for that addressing, so they are handed ld.
+int sweep_on_device(hh_ctx* c, const double* d_params, const int64_t n_cand, float* d_scores,
+                    const double* h_params = nullptr, int64_t ld = 0) {
+  RunPlan plan = plan_runs(c, h_params, n_cand);
   c->last_first_pass = plan.ok ? (plan.fused ? 2 : 1) : 0;
-  if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan, 0, g);
+  const int64_t g = ld > 0 ? ld : n_cand;
+  if (plan.ok) return sweep_runs(c, d_params, g, d_scores, plan, 0, n_cand);
   // A list that starts inside a run (a shard cut anywhere) or ends with a partial run: the whole runs in
   // the middle still take the shared-twist pipeline, the two ragged ends the general one.
-  if (h_params && c->table_path && !c->geom.has_rot && g >= 2 * HH_MIN_RUN) {
+  if (h_params && c->table_path && !c->geom.has_rot && n_cand >= 2 * HH_MIN_RUN) {
     auto same = [&](int64_t i, int64_t j) {
       return h_params[4 * i] == h_params[4 * j] && h_params[4 * i + 2] == h_params[4 * j + 2] &&
              h_params[4 * i + 3] == h_params[4 * j + 3];
     };
     int64_t head = 1;
-    while (head < g && same(head, 0)) ++head;
+    while (head < n_cand && same(head, 0)) ++head;
     int64_t len = 1;
-    while (head + len < g && same(head + len, head)) ++len;
-    const int64_t count = head < g ? (g - head) / len * len : 0;
-    if (head < g && head < len && len >= HH_MIN_RUN && count >= len) {
+    while (head + len < n_cand && same(head + len, head)) ++len;
+    const int64_t count = head < n_cand ? (n_cand - head) / len * len : 0;
+    if (head < n_cand && head < len && len >= HH_MIN_RUN && count >= len) {
       plan = plan_runs(c, h_params + 4 * head, count);
       if (plan.ok) {
         c->last_first_pass = plan.fused ? 2 : 1;
@@ -2706,23 +2764,23 @@ int sweep_on_device(hh_ctx* c, const double* d_params, int64_t g, float* d_score
         if (rc) return rc;
         rc = sweep_runs(c, d_params, g, d_scores, plan, head, count);
         if (rc) return rc;
-        return head + count < g ? sweep_transform(c, d_params, g, d_scores, head + count, g - head - count) : HH_OK;
+        return head + count < n_cand ? sweep_transform(c, d_params, g, d_scores, head + count, n_cand - head - count) : HH_OK;
       }
     }
     // aligned start, partial last run
     len = head;
-    const int64_t whole = g / len * len;
-    if (len >= HH_MIN_RUN && whole >= len && whole < g) {
+    const int64_t whole = n_cand / len * len;
+    if (len >= HH_MIN_RUN && whole >= len && whole < n_cand) {
       plan = plan_runs(c, h_params, whole);
       if (plan.ok) {
         c->last_first_pass = plan.fused ? 2 : 1;
         const int rc = sweep_runs(c, d_params, g, d_scores, plan, 0, whole);
         if (rc) return rc;
-        return sweep_transform(c, d_params, g, d_scores, whole, g - whole);
+        return sweep_transform(c, d_params, g, d_scores, whole, n_cand - whole);
       }
     }
   }
-  return sweep_transform(c, d_params, g, d_scores, 0, g);
+  return sweep_transform(c, d_params, g, d_scores, 0, n_cand);
 }
 
 int check_ready(hh_ctx* c, bool need_ref) {
@@ -2745,11 +2803,11 @@ int pair_reduce(hh_ctx* c, const T* a, const T* b, int64_t n, double mx, double 
   const int grid = (int)std::min<int64_t>(1024, (n + 255) / 256);
   T *da = nullptr, *db = nullptr;
   double* dp = nullptr;
-  HH_HIP(c, hipMalloc(&da, n * sizeof(T)));
-  HH_HIP(c, hipMalloc(&db, n * sizeof(T)));
-  HH_HIP(c, hipMalloc(&dp, (size_t)grid * 5 * sizeof(double)));
   std::vector<double> hp((size_t)grid * 5);
-  hipError_t e = hipMemcpyAsync(da, a, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
+  hipError_t e = hipMalloc(&da, n * sizeof(T));
+  if (e == hipSuccess) e = hipMalloc(&db, n * sizeof(T));
+  if (e == hipSuccess) e = hipMalloc(&dp, (size_t)grid * 5 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(da, a, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(db, b, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL((k_pair_sums<T>), dim3(grid), dim3(256), 0, c->stream, da, db, n, mx, my, dp);
@@ -2901,6 +2959,7 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_eg);
   (void)hipFree(c->d_cgs);
   (void)hipFree(c->d_run_imax);
+  (void)hipFree(c->d_argmax);
 
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
@@ -3066,30 +3125,25 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     }
     c->ref[s] = RefConsts{sw, swec, var_e};
   }
-  for (void* p : {(void*)c->d_w2, (void*)c->d_wec, (void*)c->d_q, (void*)c->d_cpart, (void*)c->d_ref, (void*)c->d_psum})
-    if (p) HH_HIP(c, hipFree(p));
-  c->d_w2 = nullptr;
-  c->d_wec = nullptr;
-  c->d_q = nullptr;
-  c->d_cpart = nullptr;
-  c->d_ref = nullptr;
-  c->d_psum = nullptr;
-  HH_HIP(c, hipMalloc(&c->d_w2, w2.size() * sizeof(float2)));
+  // From here on the old reference is gone: a failure below leaves the context in the "no reference" state (the next
+  // sweep returns HH_ERR_STATE) instead of a mix of old sizes and new tables.  The device tables are kept between
+  // calls and only grow.
+  c->n_segments = 0;
+  int rcg = ensure_bytes(c, (void**)&c->d_w2, &c->cap_w2, w2.size() * sizeof(float2));
+  if (rcg) return rcg;
   HH_HIP(c, hipMemcpyAsync(c->d_w2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
   if (multi) {
-    HH_HIP(c, hipMalloc(&c->d_wec, wecm.size() * sizeof(float)));
-    HH_HIP(c, hipMalloc(&c->d_q, (size_t)b_pad * nh * sizeof(float)));
-    HH_HIP(c, hipMalloc(&c->d_cpart, (size_t)(n / 2 + 1) * b_pad * s_pad * sizeof(float)));
-    HH_HIP(c, hipMalloc(&c->d_ref, (size_t)n_segments * sizeof(RefConsts)));
-    HH_HIP(c, hipMalloc(&c->d_psum, (size_t)b_pad * 3 * sizeof(double)));  // one triple per candidate of a batch
+    if ((rcg = ensure_bytes(c, (void**)&c->d_wec, &c->cap_wec, wecm.size() * sizeof(float)))) return rcg;
+    if ((rcg = ensure_bytes(c, (void**)&c->d_q, &c->cap_q, (size_t)b_pad * nh * sizeof(float)))) return rcg;
+    if ((rcg = ensure_bytes(c, (void**)&c->d_cpart, &c->cap_cpart, (size_t)(n / 2 + 1) * b_pad * s_pad * sizeof(float)))) return rcg;
+    if ((rcg = ensure_bytes(c, (void**)&c->d_ref, &c->cap_ref, (size_t)n_segments * sizeof(RefConsts)))) return rcg;
+    if ((rcg = ensure_bytes(c, (void**)&c->d_psum, &c->cap_psum, (size_t)b_pad * 3 * sizeof(double)))) return rcg;  // one triple per candidate of a batch
     HH_HIP(c, hipMemcpyAsync(c->d_wec, wecm.data(), wecm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HH_HIP(c, hipMemcpyAsync(c->d_ref, c->ref.data(), (size_t)n_segments * sizeof(RefConsts), hipMemcpyHostToDevice,
                              c->stream));
     HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)b_pad * nh * sizeof(float), c->stream));  // pad rows stay finite
   }
-  if (c->d_kb_list) HH_HIP(c, hipFree(c->d_kb_list));
-  c->d_kb_list = nullptr;
-  HH_HIP(c, hipMalloc(&c->d_kb_list, kb_list.size() * sizeof(int)));
+  if ((rcg = ensure_bytes(c, (void**)&c->d_kb_list, &c->cap_kb, (size_t)(n / 16) * sizeof(int)))) return rcg;
   HH_HIP(c, hipMemcpyAsync(c->d_kb_list, kb_list.data(), kb_list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   // rows of skipped ky blocks keep zero moments
   HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)2 * c->cap_partials * npart_for(n) * 3 * sizeof(double), c->stream));
@@ -3119,6 +3173,16 @@ int hh_sweep_device_mirrored(hh_ctx* c, const double* d_params, const double* h_
   if (g == 0) return HH_OK;
   HH_HIP(c, hipSetDevice(c->device));
   return sweep_on_device(c, d_params, g, d_scores, h_params);
+}
+
+int hh_sweep_device_strided(hh_ctx* c, const double* d_params, const double* h_params, int64_t g, float* d_scores,
+                            int64_t ld_scores) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (!d_params || !d_scores || g < 0 || ld_scores < g) return fail(c, HH_ERR_ARG, "hh_sweep_device_strided: bad argument");
+  if (g == 0) return HH_OK;
+  HH_HIP(c, hipSetDevice(c->device));
+  return sweep_on_device(c, d_params, g, d_scores, h_params, ld_scores);
 }
 
 int hh_last_first_pass(const hh_ctx* c) { return c ? c->last_first_pass : HH_ERR_ARG; }
@@ -3174,6 +3238,25 @@ int hh_argmax(const float* scores, int64_t n, int64_t* index) {
     if (best < 0 || scores[i] > scores[best]) best = i;
   }
   *index = best < 0 ? 0 : best;
+  return HH_OK;
+}
+
+int hh_argmax_device(hh_ctx* c, const float* d_scores, int64_t n_rows, int64_t n, int64_t ld, int64_t* d_index,
+                     int64_t* h_index) {
+  if (!c || !d_scores || (!d_index && !h_index) || n_rows <= 0 || n <= 0 || n_rows > 65535 || (ld != 0 && ld < n))
+    return fail(c, HH_ERR_ARG, "hh_argmax_device: bad argument");
+  HH_HIP(c, hipSetDevice(c->device));
+  if (!d_index) {
+    int rc = ensure_bytes(c, (void**)&c->d_argmax, &c->cap_argmax, (size_t)n_rows * sizeof(int64_t));
+    if (rc) return rc;
+    d_index = c->d_argmax;
+  }
+  hipLaunchKernelGGL(k_argmax_rows, dim3((unsigned)n_rows), dim3(1024), 0, c->stream, d_scores, n, ld ? ld : n, d_index);
+  HH_HIP(c, hipGetLastError());
+  if (h_index) {
+    HH_HIP(c, hipMemcpyAsync(h_index, d_index, (size_t)n_rows * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HH_HIP(c, hipStreamSynchronize(c->stream));
+  }
   return HH_OK;
 }
 

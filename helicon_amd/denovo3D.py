@@ -14,6 +14,7 @@ there is no NumPy/SciPy fallback — without the library or a GPU these function
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import threading
 from dataclasses import dataclass
@@ -61,8 +62,11 @@ def units_to_cylindrical(centers_0: np.ndarray) -> np.ndarray:
 
 
 class SweepEngine:
-    """One ``hh_ctx``: a device, an image side, device workspaces.  Not thread-safe by itself;
-    calls are serialised with a lock (the reference calls its task function from pool threads)."""
+    """One ``hh_ctx``: a device, an image side, device workspaces.  The context itself is not
+    thread-safe; every call takes the engine's re-entrant lock, and a caller that configures and then
+    scores (geometry, reference, sweep) holds it across the whole sequence with ``session()`` — the
+    reference calls its task function from pool threads (app.py:2473-2476), and two threads with
+    different images must not interleave between ``set_reference`` and ``sweep``."""
 
     def __init__(self, n: int, device: int = 0, max_batch: int = 0):
         if n not in _SUPPORTED_N:
@@ -71,11 +75,18 @@ class SweepEngine:
         self._ctx = C.c_void_p()
         self.n = int(n)
         self.device = int(device)
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()
         _lib.check(self._L.hh_create(C.byref(self._ctx), self.device, self.n, int(max_batch)), None)
         self.max_batch = int(self._L.hh_max_batch(self._ctx))
         self.n_segments = 0
         self._geom_key = None
+        self._ref_key = None
+
+    @contextlib.contextmanager
+    def session(self):
+        """Hold the engine for a configure-and-score sequence (re-entrant)."""
+        with self._lock:
+            yield self
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -112,8 +123,6 @@ class SweepEngine:
                      units=None, tail_bits=0):
         key = (float(apix), float(helical_diameter), float(ball_radius), float(tilt), float(psi), float(dy),
                None if units is None else np.asarray(units, dtype=np.float64).tobytes(), int(tail_bits))
-        if key == self._geom_key:
-            return
         # the reference asserts (utils.py:88); keep its exception type
         assert helical_diameter + ball_radius < self.n * apix * 0.99
         g = _lib.hh_geom()
@@ -128,11 +137,20 @@ class SweepEngine:
         else:
             g.n_units = 0
             g.units = None
-        with self._lock:
+        with self._lock:  # compare-and-set under the lock
+            if key == self._geom_key:
+                return
+            self._geom_key = None
             self._check(self._L.hh_set_geometry(self._ctx, C.byref(g)))
-        self._geom_key = key
+            self._geom_key = key
 
-    def set_reference(self, images, mask=None, log=True):
+    def set_reference(self, images, mask=None, log=True, key=None):
+        """``key``: an optional hashable identity of (images, mask, log); when it equals the key of the
+        reference the context already holds, the upload and the spectrum preparation are skipped."""
+        if key is not None:
+            with self._lock:
+                if key == self._ref_key:
+                    return
         imgs = _f32(images)
         if imgs.ndim == 2:
             imgs = imgs[None]
@@ -144,9 +162,17 @@ class SweepEngine:
         if m.shape != (self.n, self.n):
             raise ValueError(f"mask must be [{self.n}, {self.n}] on the fftshifted plane")
         with self._lock:
-            self._check(self._L.hh_set_reference(self._ctx, _ptr(imgs, C.c_float), imgs.shape[0],
-                                                 _ptr(m, C.c_uint8), 1 if log else 0))
-        self.n_segments = imgs.shape[0]
+            try:
+                self._check(self._L.hh_set_reference(self._ctx, _ptr(imgs, C.c_float), imgs.shape[0],
+                                                     _ptr(m, C.c_uint8), 1 if log else 0))
+            except ValueError:  # HH_ERR_ARG: rejected before anything changed, the old reference stands
+                raise
+            except Exception:   # the library dropped the old reference (sweeps now report HH_ERR_STATE)
+                self.n_segments = 0
+                self._ref_key = None
+                raise
+            self.n_segments = imgs.shape[0]
+            self._ref_key = key
 
     # -- the hot path -----------------------------------------------------------------------
     def sweep(self, params) -> np.ndarray:
@@ -157,21 +183,43 @@ class SweepEngine:
             self._check(self._L.hh_sweep(self._ctx, _ptr(p, C.c_double), len(p), _ptr(out, C.c_float)))
         return out
 
-    def sweep_device(self, d_params: int, n_candidates: int, d_scores: int, host_params=None):
+    def sweep_device(self, d_params: int, n_candidates: int, d_scores: int, host_params=None, ld_scores: int = 0):
         """Device pointers (ints): params [G, 4] float64, scores [S, G] float32; asynchronous on
         the engine's stream.  ``host_params`` = the same [G, 4] list on the host, if the caller has
         it: it lets the library take the shared-twist first pass on twist-major grids
-        (``hh_sweep_device_mirrored``)."""
+        (``hh_sweep_device_mirrored``).  ``ld_scores`` > G: row stride of the score buffer
+        (``hh_sweep_device_strided``), e.g. the padded send buffer of an all-gather."""
         with self._lock:
-            if host_params is None:
-                self._check(self._L.hh_sweep_device(self._ctx, C.c_void_p(d_params), int(n_candidates),
-                                                    C.c_void_p(d_scores)))
-            else:
+            hp = None
+            if host_params is not None:
                 hp = np.ascontiguousarray(host_params, dtype=np.float64)
                 if hp.shape != (int(n_candidates), 4):
                     raise ValueError("host_params must be [n_candidates, 4]")
+            if ld_scores:
+                self._check(self._L.hh_sweep_device_strided(self._ctx, C.c_void_p(d_params),
+                                                            _ptr(hp, C.c_double) if hp is not None else None,
+                                                            int(n_candidates), C.c_void_p(d_scores), int(ld_scores)))
+            elif hp is None:
+                self._check(self._L.hh_sweep_device(self._ctx, C.c_void_p(d_params), int(n_candidates),
+                                                    C.c_void_p(d_scores)))
+            else:
                 self._check(self._L.hh_sweep_device_mirrored(self._ctx, C.c_void_p(d_params), _ptr(hp, C.c_double),
                                                              int(n_candidates), C.c_void_p(d_scores)))
+
+    def argmax_device(self, d_scores: int, n_rows: int, n: int, ld: int = 0, d_index: int | None = None):
+        """Per-row arg-max of device-resident scores (row r at ``d_scores + r * ld``; lowest index on ties, NaN
+        never wins).  With ``d_index`` (a device int64 buffer) the call is asynchronous and returns None;
+        otherwise the indices come back as a NumPy array."""
+        if d_index is not None:
+            with self._lock:
+                self._check(self._L.hh_argmax_device(self._ctx, C.c_void_p(d_scores), int(n_rows), int(n), int(ld),
+                                                     C.c_void_p(d_index), None))
+            return None
+        out = np.zeros(int(n_rows), dtype=np.int64)
+        with self._lock:
+            self._check(self._L.hh_argmax_device(self._ctx, C.c_void_p(d_scores), int(n_rows), int(n), int(ld),
+                                                 None, _ptr(out, C.c_int64)))
+        return out
 
     def set_table_path(self, mode=2):
         """How runs of candidates that share (twist, csym, rot) are swept: 0 / False = like any other
@@ -323,14 +371,16 @@ def simulate_helical_projection(n, twist, rise, csym, helical_diameter, ball_rad
         angle = np.random.uniform(-np.pi, np.pi, n)
         z = np.random.uniform(-rise / 2, rise / 2, n)
         units = np.stack([r, angle, z], axis=1)
-    eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
-                     tilt=tilt, psi=psi, dy=dy, units=units)
-    return eng.simulate(twist, rise, int(csym), float(rot)).astype(np.float64)
+    with eng.session():
+        eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
+                         tilt=tilt, psi=psi, dy=dy, units=units)
+        return eng.simulate(twist, rise, int(csym), float(rot)).astype(np.float64)
 
 
 def compute_power_spectra(data, apix, cutoff_res=None, output_size=None, log=True,
                           low_pass_fraction=0, high_pass_fraction=0, *, device=0):
-    """transforms.py:771-779 for the default Fourier sampling; returns ``(pwr, phase)``."""
+    """transforms.py:771-820 for the default Fourier sampling (no ``cutoff_res`` / ``output_size`` zoom);
+    returns ``(pwr, phase)``."""
     data = np.asarray(data)
     if data.ndim != 2:
         raise NotImplementedError("only 2D images are on the accelerated path")
@@ -338,10 +388,17 @@ def compute_power_spectra(data, apix, cutoff_res=None, output_size=None, log=Tru
         raise NotImplementedError("Fourier-space zoom (cutoff_res) is outside the accelerated path")
     if output_size is not None and tuple(output_size) != tuple(data.shape):
         raise NotImplementedError("Fourier-space zoom (output_size) is outside the accelerated path")
-    if 0 < low_pass_fraction < 1 or 0 < high_pass_fraction < 1:
-        raise NotImplementedError("low/high-pass filtering of the spectrum is outside the accelerated path")
     side = _square_side(*data.shape)
-    pwr, phase = _engine(side, device).power_spectrum(data, log=log, want_phase=True)
+    eng = _engine(side, device)
+    with eng.session():
+        pwr, phase = eng.power_spectrum(data, log=log, want_phase=True)
+        if 0 < low_pass_fraction < 1 or 0 < high_pass_fraction < 1:
+            # transforms.py:811-817 filters log1p|F| and then min-max normalises.  The device spectrum is already
+            # normalised, x -> a x + b with a > 0; the filter maps the constant b to another constant and min-max
+            # normalisation removes any positive affine map, so normalise(filter(a x + b)) = normalise(filter(x)).
+            f = eng.low_high_pass_filter(pwr, low_pass_fraction, high_pass_fraction)
+            vmin, vmax = float(f.min()), float(f.max())
+            pwr = (f - vmin) / (vmax - vmin) if vmax != vmin else f  # filters.py:276-280
     return pwr.astype(np.float64), phase.astype(np.float64)
 
 
@@ -441,19 +498,63 @@ def sweep(images, twists, rises, csyms=(1,), *, apix, helical_diameter, ball_rad
     side = _square_side(*imgs.shape[-2:])
     eng = engine or _engine(side, device)
     grid = build_grid(twists, rises, csyms, tube_length=side * apix, rot=rot)
-    eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
-                     tilt=tilt, psi=psi, dy=dy)
-    eng.set_reference(imgs, mask, log=log)
     from .distributed import harmless_rise
 
     params = grid.params.copy()
     params[~grid.valid, 1] = harmless_rise(grid)  # skipped pairs still occupy a slot
-    return finish_sweep(eng.sweep(params), grid)
+    with eng.session():
+        eng.set_geometry(apix=apix, helical_diameter=helical_diameter, ball_radius=ball_radius,
+                         tilt=tilt, psi=psi, dy=dy)
+        eng.set_reference(imgs, mask, log=log)
+        scores = eng.sweep(params)
+    return finish_sweep(scores, grid)
 
 
 # ------------------------------------------------------------------------------------------
 # pipeline.process_one_task tuple layout (pipeline.py:85-122, 469-497), Path-B scoring
 # ------------------------------------------------------------------------------------------
+def _digest(a: np.ndarray) -> tuple:
+    """Content identity of an array (shape, dtype, 64-bit hash of the bytes)."""
+    a = np.ascontiguousarray(a)
+    buf = memoryview(a).cast("B")
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_64_intdigest(buf)
+    except ImportError:  # pragma: no cover - xxhash ships with the image
+        import hashlib
+
+        h = hashlib.sha1(buf).digest()
+    return (a.shape, a.dtype.str, h)
+
+
+_prepared: dict = {}          # (image digest, preparation options) -> prepared float image
+_blank: dict = {}             # image digest -> np.std(image) == 0
+_prepared_lock = threading.Lock()
+_PREPARED_MAX = 16
+
+
+def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_diameter, device):
+    """The part of pipeline.py:180-286 the accelerated path provides, on one image: Gaussian low / high
+    pass (pipeline.py:183-188), transpose (:202-203), background subtraction + threshold + /max
+    (:277-284).  Unlike the reference (pipeline.py:282 works in place when no rescale happened) the
+    caller's array is never modified."""
+    if low_pass is not None and low_pass > 2 * apix:
+        data = low_high_pass_filter(data, low_pass_fraction=2 * apix / low_pass,
+                                    high_pass_fraction=2.0 / np.max(data.shape), device=device)
+    if transpose is not None and transpose > 0:  # transpose < 0 = "if vertical" needs is_vertical (skimage)
+        data = data.T
+    ny, nx = data.shape
+    if thresh_fraction is not None and thresh_fraction >= 0:
+        # pipeline.py:253-255: reconstruct_diameter = tube_diameter if 0 < tube_diameter < ny*apix else ny*apix
+        rec_d = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
+        nr = min(ny // 2 - 1, int(np.ceil(rec_d / 2 / apix) + 1))
+        data = np.asarray(data, dtype=np.float64) - np.median(np.asarray(data)[(ny // 2 - nr, ny // 2 + nr), :])
+        data = threshold_data(data, thresh_fraction=thresh_fraction, device=device)
+        data = data / np.max(data)
+    return data
+
+
 def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range,
                      psi, psi_range, dy, dy_range, apix2d_orig, denoise, low_pass, transpose, horizontalize,
                      target_apix3d, target_apix2d, thresh_fraction, positive_constraint, tube_length,
@@ -464,44 +565,68 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
     ``None`` for a blank image (pipeline.py:214-218), else
     ``(score, (None, None, None, None, D2d, D3d, L2d, L3d), (data, imageFile, imageIndex, apix3d,
     apix2d, twist, rise, csym, tilt, psi, dy))``.  ``algorithm`` may carry ``helical_diameter``,
-    ``ball_radius``, ``mask`` and ``log``; image preparation options of the reference that need
-    scikit-image (denoise, horizontalize, rescaling) are rejected."""
+    ``ball_radius``, ``mask``, ``log`` and ``device``.  ``imageIndex`` is 1-based like the reference's
+    (pipeline.py:212 reads ``imageIndex - 1``).  ``target_apix2d`` below the image's own pixel size means
+    "no rescale" (pipeline.py:268-272, filters.py:393-409); a larger one needs scikit-image's ``rescale``
+    and is rejected, like denoise / horizontalize / auto tube diameter.
+
+    The reference's pool calls this once per (twist, rise) pair with the same image (app.py:2473-2476): the
+    prepared image is cached by content, and the engine keeps the reference spectrum it was last given, so
+    repeated calls cost one 1-candidate sweep each."""
     if data is None:  # pipeline.py:211-212
         from .mrc import read_image_2d
 
-        data = read_image_2d(imageFile, imageIndex)
+        data = read_image_2d(imageFile, imageIndex - 1)
     data = np.asarray(data)
-    if np.std(data) == 0:
+    dkey = _digest(data)
+    with _prepared_lock:
+        blank = _blank.get(dkey)
+    if blank is None:
+        blank = bool(np.std(data) == 0)
+        with _prepared_lock:
+            if len(_blank) >= 4 * _PREPARED_MAX:
+                _blank.clear()
+            _blank[dkey] = blank
+    if blank:  # pipeline.py:214-218
         return None
     if denoise or horizontalize:
         raise NotImplementedError("denoise / horizontalize need scikit-image and are outside the accelerated path")
-    if target_apix2d is not None and target_apix2d > 0 and abs(target_apix2d - apix2d_orig) > 1e-6:
-        raise NotImplementedError("rescaling to target_apix2d is outside the accelerated path")
+    if transpose is not None and transpose < 0:
+        raise NotImplementedError("transpose < 0 (transpose if vertical) needs is_vertical and is outside the accelerated path")
+    if tube_diameter is not None and tube_diameter < 0:
+        raise NotImplementedError("auto tube diameter (estimate_helix_rotation_center_diameter) needs scikit-image")
     apix = float(apix2d_orig)
+    if target_apix2d is None or target_apix2d < apix:  # pipeline.py:268-269
+        target_apix2d = apix
+    if target_apix2d > apix + 1e-9:
+        raise NotImplementedError("down-scaling to target_apix2d > apix2d_orig needs scikit-image's rescale")
     opts = dict(algorithm or {})
-    if low_pass is not None and low_pass > 2 * apix:  # pipeline.py:183-188
-        data = low_high_pass_filter(data, low_pass_fraction=2 * apix / low_pass,
-                                    high_pass_fraction=2.0 / np.max(data.shape), device=int(opts.get("device", 0)))
-    if transpose is not None and transpose > 0:  # pipeline.py:202-203 (transpose < 0 = "if vertical" needs is_vertical)
-        data = data.T
-    ny, nx = data.shape
+    device = int(opts.get("device", 0))
+    mask = opts.get("mask")
+    log = bool(opts.get("log", True))
+    pkey = (dkey, apix, None if low_pass is None else float(low_pass), None if transpose is None else int(transpose > 0),
+            None if thresh_fraction is None else float(thresh_fraction), float(tube_diameter), device)
+    with _prepared_lock:
+        prepared = _prepared.get(pkey)
+    if prepared is None:
+        prepared = _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_diameter, device)
+        with _prepared_lock:
+            if len(_prepared) >= _PREPARED_MAX:
+                _prepared.pop(next(iter(_prepared)))
+            _prepared[pkey] = prepared
+    ny, nx = prepared.shape
     side = _square_side(ny, nx)
-    if thresh_fraction is not None and thresh_fraction >= 0:  # pipeline.py:277-284
-        # pipeline.py:253-255: reconstruct_diameter = tube_diameter if 0 < tube_diameter < ny*apix else ny*apix
-        rec_d = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
-        nr = min(ny // 2 - 1, int(np.ceil(rec_d / 2 / apix) + 1))
-        data = np.asarray(data, dtype=np.float64) - np.median(np.asarray(data)[(ny // 2 - nr, ny // 2 + nr), :])
-        data = threshold_data(data, thresh_fraction=thresh_fraction, device=int(opts.get("device", 0)))
-        data = data / np.max(data)
     diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))
     ball_radius = float(opts.get("ball_radius", 2.0 * apix))
-    eng = _engine(side, int(opts.get("device", 0)))
-    eng.set_geometry(apix=apix, helical_diameter=diameter, ball_radius=ball_radius, tilt=tilt, psi=psi, dy=dy)
-    eng.set_reference(data, opts.get("mask"), log=bool(opts.get("log", True)))
-    score = float(eng.sweep(np.array([[twist, rise, csym, 0.0]]))[0, 0])
+    rkey = (pkey, None if mask is None else _digest(np.asarray(mask) != 0), log)
+    eng = _engine(side, device)
+    with eng.session():
+        eng.set_geometry(apix=apix, helical_diameter=diameter, ball_radius=ball_radius, tilt=tilt, psi=psi, dy=dy)
+        eng.set_reference(prepared, mask, log=log, key=rkey)
+        score = float(eng.sweep(np.array([[twist, rise, csym, 0.0]]))[0, 0])
     apix3d = target_apix3d if (target_apix3d is not None and target_apix3d > 0) else apix
     return (
         score,
         (None, None, None, None, nx, ny, nx, nx),
-        (data, imageFile, imageIndex, apix3d, apix, twist, rise, csym, tilt, psi, dy),
+        (prepared, imageFile, imageIndex, apix3d, apix, twist, rise, csym, tilt, psi, dy),
     )

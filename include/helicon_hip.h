@@ -130,6 +130,11 @@ int hh_sweep_device(hh_ctx* ctx, const double* d_params, int64_t n_candidates, f
  * fits (default). */
 int hh_sweep_device_mirrored(hh_ctx* ctx, const double* d_params, const double* h_params, int64_t n_candidates,
                              float* d_scores);
+/* hh_sweep_device_mirrored with a row stride for the scores: segment s of candidate i is written to
+ * d_scores[s * ld_scores + i], ld_scores >= n_candidates.  Lets a multi-GPU caller sweep straight into the
+ * padded send buffer of its score all-gather (helicon_amd/distributed.py).  h_params may be NULL. */
+int hh_sweep_device_strided(hh_ctx* ctx, const double* d_params, const double* h_params, int64_t n_candidates,
+                            float* d_scores, int64_t ld_scores);
 int hh_set_table_path(hh_ctx* ctx, int mode);
 /* Which pipeline the last sweep of this context ran: 0 = per-candidate raster + column transform +
  * second pass, 1 = run tables + second pass, 2 = fused. */
@@ -147,6 +152,14 @@ int hh_threshold_data(hh_ctx* ctx, const float* data, int64_t n, int use_fractio
 
 /* arg-max with ties resolved to the lowest index (np.argmax); NaN never wins. */
 int hh_argmax(const float* scores, int64_t n, int64_t* index);
+
+/* The same rule for device-resident scores: row r (a segment of a sweep's S x G output, or one rank's
+ * block of an all-gathered buffer) is d_scores[r * ld .. r * ld + n), ld = 0 meaning n.  One reduction kernel on
+ * the context's stream writes n_rows indices to d_index (device; NULL = a buffer of the context); when h_index
+ * is not NULL they are also copied to the host and the call returns after they have arrived, otherwise the
+ * call is asynchronous.  Replaces pulling S x G floats to the host for S indices. */
+int hh_argmax_device(hh_ctx* ctx, const float* d_scores, int64_t n_rows, int64_t n, int64_t ld, int64_t* d_index,
+                     int64_t* h_index);
 
 /* One simulated projection (host, N x N float32) for params[4] = (twist, rise, csym, rot). */
 int hh_simulate(hh_ctx* ctx, const double* params, float* image_out);
