@@ -80,6 +80,15 @@
 #ifndef HH_FFT_SWZ
 #define HH_FFT_SWZ 1       // xor-swizzled slots for the first exchange of every transform (bank conflicts)
 #endif
+#ifndef HH_FFT_SWZ2
+#define HH_FFT_SWZ2 1      // second exchange of the 512 / 1024-point transforms kept in bank-conflict-free slots
+#endif
+#ifndef HH_KF_PSWZ
+#define HH_KF_PSWZ 1       // fused pass: 16-byte chunks of the panel row xor-swizzled (conflict-free b128 stores)
+#endif
+#ifndef HH_XCD_MAP
+#define HH_XCD_MAP 1       // fused pass: all ky blocks of a layer of candidates on one XCD (shared L2)
+#endif
 #ifndef HH_KB_WPS
 #define HH_KB_WPS 4        // K_B: waves per SIMD the register allocator must leave room for
 #endif
@@ -242,6 +251,12 @@ template <int N, int R, int NS, bool LAST, int OFF, int LOFF, bool SWZ1, typenam
 __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   constexpr int T = N / 8, NB = 8 / R, E = imin(NS, T);
   constexpr bool SWZ = SWZ1 && NS == 1 && R == 8 && !LAST && N >= 128;
+  // second exchange (NS = 8, R = 8): lane j writes out[64 (j >> 3) + (j & 7) + 8 r]; lanes j and j + 8 of a 16-lane
+  // ds_write_b64 group are 512 bytes apart = the same banks (2-way conflict on all eight stores).  Element o is
+  // therefore kept in slot o ^ (((o >> 6) & 1) << 3): the writer's r becomes r ^ b with b = (j >> 3) & 1, i.e. even r
+  // go to base + 8 b + 8 r and odd r to base - 8 b + 8 r (two base registers, the immediates stay), and the reader of
+  // element n = t + m T looks in n ^ (((n >> 6) & 1) << 3).  No extra vector instructions.
+  constexpr bool SWZ2 = SWZ1 && HH_FFT_SWZ2 && NS == 8 && R == 8 && !LAST && NB == 1 && (T == 64 || T == 128);
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     float2 a[R];
@@ -264,6 +279,13 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
       char* const base = reinterpret_cast<char*>(buf);
 #pragma unroll
       for (int r = 0; r < R; ++r) *reinterpret_cast<float2*>(base + (bs ^ (unsigned)(r << 3))) = a[r];
+    } else if constexpr (SWZ2) {
+      const int j = t;  // NB == 1
+      const int k = j & 7, b8 = ((j >> 3) & 1) * 8;
+      float2* const we = buf + (j - k) * 8 + k + b8;  // even r
+      float2* const wo = buf + (j - k) * 8 + k - b8;  // odd r
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ((r & 1) ? wo : we)[r * 8] = a[r];
     } else {
       const int j = t + q * T;
       const int k = j & (NS - 1);
@@ -274,7 +296,17 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
   }
   if constexpr (!LAST) {
     group_sync<T>();
-    if constexpr (SWZ) {
+    if constexpr (SWZ2) {
+      if constexpr (T == 64) {  // (n >> 6) & 1 = m & 1
+        const int e0 = t, e1 = t ^ 8;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[((m & 1) ? e1 : e0) + m * T];
+      } else {                  // T = 128: (n >> 6) & 1 = (t >> 6) & 1 for every m
+        const int e0 = t ^ (((t >> 6) & 1) << 3);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[e0 + m * T];
+      }
+    } else if constexpr (SWZ) {
       // element n = t + m T sits in slot (n & ~7) | ((n & 7) ^ ((n >> 4) & 7))
       if constexpr (T == 64) {  // (n >> 4) & 7 = (t >> 4) ^ 4 (m & 1): two bases, immediate offsets
         const int e0 = (t & ~7) | ((t & 7) ^ (t >> 4)), e1 = e0 ^ 4;
@@ -311,10 +343,10 @@ __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, f
   if constexpr (P::n == 2) {
     fft_stage<N, P::r1, P::r0, true, W::off1, W::lds1, false>(v, tw, t, buf);
   } else if constexpr (P::n == 3) {
-    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, false>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, SWZ1>(v, tw, t, buf);
     fft_stage<N, P::r2, P::r0 * P::r1, true, W::off2, W::lds2, false>(v, tw, t, buf);
   } else {
-    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, false>(v, tw, t, buf);
+    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, SWZ1>(v, tw, t, buf);
     fft_stage<N, P::r2, P::r0 * P::r1, false, W::off2, W::lds2, false>(v, tw, t, buf);
     fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, W::off3, W::lds3, false>(v, tw, t, buf);
   }
@@ -1403,6 +1435,23 @@ struct FusedArgs {
 typedef __attribute__((address_space(1))) const void* gptr_t;  // operands of __builtin_amdgcn_global_load_lds
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// One LDS-DMA wave-instruction: every active lane moves 16 bytes from its own global address to
+// lds_base + 16 * lane (lds_base wave-uniform).  Issued through inline assembly on purpose: for the builtin, the
+// compiler's alias tracking of LDS-DMA cannot tell the factor buffer being filled from the one being read and puts a
+// conservative s_waitcnt vmcnt(0) in front of the next ds_read, which serialises the copy with the transform it is
+// meant to fly under.  Here the compiler does not see the LDS write at all, so the CALLER orders it: s_waitcnt
+// vmcnt(0) (lds_dma_wait) and then a workgroup barrier before any wave reads the destination.
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gsrc_lane), "s"(lds_base)
+               : "memory");  // (M0 is a reserved register: the compiler sets it next to each of its own uses)
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {  // wave-uniform LDS byte address as a scalar
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(const_cast<void*>(p)));
+}
+
 template <int N>
 struct KF {
   static constexpr int T = N / 8;
@@ -1438,8 +1487,24 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   }
   const int gi = tid / T, t = tid % T;
   float2* const buf = bufs + gi * K::BROW;
-  const int gy = blockIdx.y - a.factor_layers - (a.fin.n > 0 ? 1 : 0);
-  const int kb = a.kb_list ? a.kb_list[blockIdx.x] : (int)blockIdx.x;
+  // Work layers -> (layer of candidates gy, ky block): workgroups are dealt round-robin over the 8 XCDs in dispatch
+  // order, so ids that are equal mod 8 share an L2.  Every ky block of one layer reads the same column factors and
+  // neighbouring 64-byte pieces of the same table rows; mapping a layer's blocks to ids of ONE residue class lets the
+  // XCD's L2 fetch them once instead of all eight L2s once each (placement is a speed matter only).
+  int gy = blockIdx.y - a.factor_layers - (a.fin.n > 0 ? 1 : 0);
+  int kbi = blockIdx.x;
+#if HH_XCD_MAP
+  {
+    const int nkb = gridDim.x, work_layers = gridDim.y - a.factor_layers - (a.fin.n > 0 ? 1 : 0);
+    const int lw = gy * nkb + kbi;
+    if (lw < (work_layers & ~7) * nkb) {
+      const int seq = lw >> 3;
+      gy = (seq / nkb) * 8 + (lw & 7);
+      kbi = seq % nkb;
+    }
+  }
+#endif
+  const int kb = a.kb_list ? a.kb_list[kbi] : kbi;
   const int row = kb * 8 + gi;
   const int run = gy / a.groups_per_run;
   const int off = (gy % a.groups_per_run) * a.cpw;
@@ -1504,42 +1569,64 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       char* const ldst = reinterpret_cast<char*>(eg + (size_t)(cur ^ 1) * a.kg * N);
       const int lane = tid & 63, wave = tid >> 6;
       for (int p0 = wave * 64; p0 < n_e4; p0 += K::THREADS)  // (a workgroup narrower than a wavefront: wave = 0)
-        if (p0 + lane < n_e4)
-          __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)(p0 + lane) * 16),
-                                           (lptr_t)(ldst + (size_t)p0 * 16), 16, 0, 0);
+        if (p0 + lane < n_e4) lds_dma16(gsrc + (size_t)(p0 + lane) * 16, lds_offset_of(ldst + (size_t)p0 * 16));
       if (wave == 0 && lane < N / 16)  // the groups' first table rows: N/4 ints
-        __builtin_amdgcn_global_load_lds(
-            (gptr_t)(reinterpret_cast<const char*>(a.cgs + (b + 1) * (N / 4)) + lane * 16),
-            (lptr_t)(reinterpret_cast<char*>(cgs + (cur ^ 1) * (N / 4))), 16, 0, 0);
+        lds_dma16(reinterpret_cast<const char*>(a.cgs + (b + 1) * (N / 4)) + lane * 16,
+                  lds_offset_of(cgs + (cur ^ 1) * (N / 4)));
     }
-    // ---- this group's row of H, built by the group itself into its own exchange buffer (no
-    // workgroup barrier): a lane takes four consecutive columns at a time
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int xg = t + pass * T;
-      const float2* const grow = gs + gi * a.rows_lds + cgc[xg];
-      const float* const erow = egc + 4 * xg;
-      float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
-      for (int k = 0; k < ((HH_ABLATE & 2048) ? 0 : a.kg); ++k) {
-        const float2 gk = grow[k];
-        const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * N);
-        acc0.x = fmaf(e4.x, gk.x, acc0.x);
-        acc0.y = fmaf(e4.x, gk.y, acc0.y);
-        acc1.x = fmaf(e4.y, gk.x, acc1.x);
-        acc1.y = fmaf(e4.y, gk.y, acc1.y);
-        acc2.x = fmaf(e4.z, gk.x, acc2.x);
-        acc2.y = fmaf(e4.z, gk.y, acc2.y);
-        acc3.x = fmaf(e4.w, gk.x, acc3.x);
-        acc3.y = fmaf(e4.w, gk.y, acc3.y);
+    // ---- this group's row of H, built by the group itself into its own exchange buffer (no workgroup barrier).
+    // A lane owns two groups of four consecutive columns (x = 4 t + c and 4 (t + T) + c): two independent
+    // accumulation chains, and the operands of the next table row are in flight while this row's FMAs issue.
+    {
+      const int xg0 = t, xg1 = t + T;
+      const float2* const grow0 = gs + gi * a.rows_lds + cgc[xg0];
+      const float2* const grow1 = gs + gi * a.rows_lds + cgc[xg1];
+      const float* const erow0 = egc + 4 * xg0;
+      const float* const erow1 = egc + 4 * xg1;
+      const int kgn = (HH_ABLATE & 2048) ? 0 : a.kg;
+      float2 p0 = make_float2(0.f, 0.f), p1 = p0, p2 = p0, p3 = p0, q0 = p0, q1 = p0, q2 = p0, q3 = p0;
+      float2 ga = grow0[0], gb = grow1[0];
+      float4 ea = *reinterpret_cast<const float4*>(erow0), eb = *reinterpret_cast<const float4*>(erow1);
+#pragma unroll 2
+      for (int k = 0; k < kgn; ++k) {
+        const int kn = min(k + 1, kgn - 1);  // the last iteration re-reads its own row: nothing past the buffers
+        const float2 gan = grow0[kn], gbn = grow1[kn];
+        const float4 ean = *reinterpret_cast<const float4*>(erow0 + (size_t)kn * N);
+        const float4 ebn = *reinterpret_cast<const float4*>(erow1 + (size_t)kn * N);
+        p0.x = fmaf(ea.x, ga.x, p0.x); p0.y = fmaf(ea.x, ga.y, p0.y);
+        p1.x = fmaf(ea.y, ga.x, p1.x); p1.y = fmaf(ea.y, ga.y, p1.y);
+        p2.x = fmaf(ea.z, ga.x, p2.x); p2.y = fmaf(ea.z, ga.y, p2.y);
+        p3.x = fmaf(ea.w, ga.x, p3.x); p3.y = fmaf(ea.w, ga.y, p3.y);
+        q0.x = fmaf(eb.x, gb.x, q0.x); q0.y = fmaf(eb.x, gb.y, q0.y);
+        q1.x = fmaf(eb.y, gb.x, q1.x); q1.y = fmaf(eb.y, gb.y, q1.y);
+        q2.x = fmaf(eb.z, gb.x, q2.x); q2.y = fmaf(eb.z, gb.y, q2.y);
+        q3.x = fmaf(eb.w, gb.x, q3.x); q3.y = fmaf(eb.w, gb.y, q3.y);
+        ga = gan; gb = gbn; ea = ean; eb = ebn;
       }
-      float4* const dst = reinterpret_cast<float4*>(buf + 4 * xg);
-      dst[0] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
-      dst[1] = make_float4(acc2.x, acc2.y, acc3.x, acc3.y);
+      // The row is handed to the transform through the group's exchange buffer.  A lane stores 2 x 32 bytes at a
+      // 32-byte lane stride: the eight lanes of a ds_write_b128 group would hit four bank groups twice, so the
+      // 16-byte chunk c = x / 2 lives at c ^ ((c >> 3) & 1) (chunks 2 xg, 2 xg + 1 of lanes xg and xg + 4 then fall
+      // into different halves of the 128-byte bank span); the reader un-swizzles with one precomputed base.
+      float4* const row4 = reinterpret_cast<float4*>(buf);
+      auto chunk = [](int c) { return HH_KF_PSWZ ? (c ^ ((c >> 3) & 1)) : c; };
+      row4[chunk(2 * xg0)] = make_float4(p0.x, p0.y, p1.x, p1.y);
+      row4[chunk(2 * xg0 + 1)] = make_float4(p2.x, p2.y, p3.x, p3.y);
+      row4[chunk(2 * xg1)] = make_float4(q0.x, q0.y, q1.x, q1.y);
+      row4[chunk(2 * xg1 + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
     }
     group_sync<T>();
     float2 v[8];
+    if constexpr (HH_KF_PSWZ && T % 32 == 0) {  // x = t + m T: bit 4 of x is bit 4 of t, one swizzled base serves every m
+      const int ps = (((t >> 1) ^ ((t >> 4) & 1)) << 1) | (t & 1);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
+      for (int m = 0; m < 8; ++m) v[m] = buf[ps + m * T];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int x = t + m * T;
+        v[m] = buf[HH_KF_PSWZ ? ((((x >> 1) ^ ((x >> 4) & 1)) << 1) | (x & 1)) : x];
+      }
+    }
     if constexpr (T > 64) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
     if (!(HH_ABLATE & 16)) fft_lanes<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
 
@@ -1619,7 +1706,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     }
     // The LDS-DMA copies of the next candidate's factors count on vmcnt only; neither the workgroup-scope fence nor
     // s_barrier waits for them, so every wavefront retires its own copies before it arrives at the barrier.
-    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) lds_dma_wait();
     __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
   }
 }

@@ -104,7 +104,7 @@ def test_power_spectrum_of_structured_image_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         H.compute_power_spectra(img, 2.0, cutoff_res=(8.0, 8.0))
     with pytest.raises(NotImplementedError):
-        H.compute_power_spectra(img, 2.0, low_pass_fraction=0.5)
+        H.compute_power_spectra(img, 2.0, output_size=(64, 64))
     with pytest.raises(ValueError):
         H.compute_power_spectra(np.zeros((48, 96), np.float32), 2.0)
 

@@ -4,7 +4,7 @@
 steps=$1; shift
 extra=$1; shift
 for lib in "$@"; do
-  HELICON_HIP_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps $steps --warmup 1 --no-cpu-baseline $extra 2>/dev/null | python -c "
+  HELICON_HIP_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-extra-legs $extra 2>/dev/null | python -c "
 import sys, json, os
 for line in sys.stdin:
     line=line.strip()
