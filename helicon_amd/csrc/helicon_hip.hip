@@ -86,6 +86,9 @@
 #ifndef HH_KF_PSWZ
 #define HH_KF_PSWZ 1       // fused pass: 16-byte chunks of the panel row xor-swizzled (conflict-free b128 stores)
 #endif
+#ifndef HH_KF_STAGGER
+#define HH_KF_STAGGER 1    // fused pass (N = 512): wavefronts 4-7 run half a candidate behind wavefronts 0-3
+#endif
 #ifndef HH_XCD_MAP
 #define HH_XCD_MAP 1       // fused pass: all ky blocks of a layer of candidates on one XCD (shared L2)
 #endif
@@ -247,7 +250,9 @@ __device__ __forceinline__ void fill_twiddles_lds(float2* lds, int t, const floa
 // in[j + r*N/R] — always the lane's own register slots v[q + r*(8/R)] — and writes
 // out[(j/NS)*NS*R + (j mod NS) + r*NS].  The last stage's outputs land back in the same slots,
 // so on return v[m] = X[t + m*T].
-template <int N, int R, int NS, bool LAST, int OFF, int LOFF, bool SWZ1, typename TW>
+// PART: 0 = the whole stage; 1 = butterflies and exchange stores only; 2 = exchange loads only (a caller may put other
+// work of the same lanes, or a workgroup barrier, between the two halves: the data is in the exchange buffer).
+template <int N, int R, int NS, bool LAST, int OFF, int LOFF, bool SWZ1, typename TW, int PART = 0>
 __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   constexpr int T = N / 8, NB = 8 / R, E = imin(NS, T);
   constexpr bool SWZ = SWZ1 && NS == 1 && R == 8 && !LAST && N >= 128;
@@ -257,6 +262,7 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
   // go to base + 8 b + 8 r and odd r to base - 8 b + 8 r (two base registers, the immediates stay), and the reader of
   // element n = t + m T looks in n ^ (((n >> 6) & 1) << 3).  No extra vector instructions.
   constexpr bool SWZ2 = SWZ1 && HH_FFT_SWZ2 && NS == 8 && R == 8 && !LAST && NB == 1 && (T == 64 || T == 128);
+  if constexpr (PART != 2) {
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     float2 a[R];
@@ -294,7 +300,8 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
       for (int r = 0; r < R; ++r) w[r * NS] = a[r];
     }
   }
-  if constexpr (!LAST) {
+  }  // PART != 2
+  if constexpr (!LAST && PART != 1) {
     group_sync<T>();
     if constexpr (SWZ2) {
       if constexpr (T == 64) {  // (n >> 6) & 1 = m & 1
@@ -335,11 +342,18 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
 // All T lanes of the transform must call it (group_sync inside; block-wide for T > 64).
 // SWZ1: xor-swizzle the first exchange (worth it where LDS time matters more than nine extra vector
 // instructions: the second pass and the fused pass; not in the raster + column-transform kernel).
+// fft_lanes in two halves: `first` runs the first stage's butterflies and leaves the data in the exchange buffer
+// (nothing of the transform lives in registers in between), `rest` picks it up there and finishes.
 template <int N, bool SWZ1 = false, typename TW>
+__device__ __forceinline__ void fft_lanes_first(float2 (&v)[8], const TW& tw, int t, float2* buf) {
+  fft_stage<N, Plan<N>::r0, 1, false, 0, 0, SWZ1, TW, 1>(v, tw, t, buf);
+}
+
+template <int N, bool SWZ1 = false, typename TW, bool RESUME = false>
 __device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   using P = Plan<N>;
   using W = TwN<N>;
-  fft_stage<N, P::r0, 1, false, 0, 0, SWZ1>(v, tw, t, buf);
+  fft_stage<N, P::r0, 1, false, 0, 0, SWZ1, TW, RESUME ? 2 : 0>(v, tw, t, buf);
   if constexpr (P::n == 2) {
     fft_stage<N, P::r1, P::r0, true, W::off1, W::lds1, false>(v, tw, t, buf);
   } else if constexpr (P::n == 3) {
@@ -1553,27 +1567,21 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   const int wave_in_row = T > 64 ? (t >> 6) : 0;
   const bool writer = (t & (TL - 1)) == group_sum_lane<TL>();
 
-#pragma unroll 1
-  for (int cc = 0; cc < nc; ++cc) {
-    const size_t b = (size_t)(cfirst + cc);
+  // One candidate = part A (build the row from the table slice and the candidate's factors, first butterflies, data
+  // left in the group's exchange buffer) + part B (rest of the transform, amplitudes, moments).  A is LDS-heavy, B is
+  // vector-heavy.  With HH_KF_STAGGER (N = 512: a transform group is one wavefront, the exchanges need no workgroup
+  // barrier) wavefronts 4-7 — the SIMD partners of 0-3 — run half a candidate behind: in round `it` wavefronts 0-3 do
+  // A(it) B(it), wavefronts 4-7 do B(it-1) A(it), so a SIMD's two wavefronts of this workgroup are in different parts
+  // most of the time instead of hitting the LDS and then the vector pipe together.  Nothing of a candidate lives in
+  // registers between A and B, and the factor buffers are used exactly as without the stagger: A(it) reads buffer
+  // it & 1 in round it, the copies for it + 1 go to the other buffer, one workgroup barrier closes the round.
+  constexpr bool STAGGER = HH_KF_STAGGER && T == 64;
+  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4;
+
+  auto part_a = [&](int cc) {
     const int cur = cc & 1;
     const float* const egc = eg + (size_t)cur * a.kg * N;
     const int* const cgc = cgs + cur * (N / 4);
-    // next candidate's column factors: copied global -> LDS by the load unit itself (no registers, no ds_write
-    // pass) into the other factor buffer, which nobody reads before the barrier at the end of this iteration
-    // (an explicit s_waitcnt vmcnt(0) ahead of that barrier retires the copies).  One wave-instruction moves
-    // 64 x 16 B to a wave-uniform LDS base + lane x 16.
-    const bool more = cc + 1 < nc && !(HH_ABLATE & 4096);
-    if (more) {
-      const char* const gsrc = reinterpret_cast<const char*>(a.eg + (b + 1) * a.kg * N);
-      char* const ldst = reinterpret_cast<char*>(eg + (size_t)(cur ^ 1) * a.kg * N);
-      const int lane = tid & 63, wave = tid >> 6;
-      for (int p0 = wave * 64; p0 < n_e4; p0 += K::THREADS)  // (a workgroup narrower than a wavefront: wave = 0)
-        if (p0 + lane < n_e4) lds_dma16(gsrc + (size_t)(p0 + lane) * 16, lds_offset_of(ldst + (size_t)p0 * 16));
-      if (wave == 0 && lane < N / 16)  // the groups' first table rows: N/4 ints
-        lds_dma16(reinterpret_cast<const char*>(a.cgs + (b + 1) * (N / 4)) + lane * 16,
-                  lds_offset_of(cgs + (cur ^ 1) * (N / 4)));
-    }
     // ---- this group's row of H, built by the group itself into its own exchange buffer (no workgroup barrier).
     // A lane owns two groups of four consecutive columns (x = 4 t + c and 4 (t + T) + c): two independent
     // accumulation chains, and the operands of the next table row are in flight while this row's FMAs issue.
@@ -1628,7 +1636,18 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       }
     }
     if constexpr (T > 64) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
-    if (!(HH_ABLATE & 16)) fft_lanes<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
+    if (!(HH_ABLATE & 16)) fft_lanes_first<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);
+  };
+
+  auto part_b = [&](int cc) {
+    const size_t b = (size_t)(cfirst + cc);
+    float2 v[8];
+    if (!(HH_ABLATE & 16)) {
+      fft_lanes<N, HH_FFT_SWZ != 0, TwRegs, true>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
+    }
 
     bool scored = false;
     if (kb == 0 && (gi == 0 || T > 64)) {
@@ -1704,11 +1723,35 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         o[2] = s3;
       }
     }
+  };
+
+#pragma unroll 1
+  for (int it = 0; it < nc; ++it) {
+    // next candidate's column factors: copied global -> LDS by the load unit itself (no registers, no ds_write
+    // pass) into the other factor buffer, which nobody reads before the barrier at the end of this round
+    // (an explicit s_waitcnt vmcnt(0) ahead of that barrier retires the copies).  One wave-instruction moves
+    // 64 x 16 B to a wave-uniform LDS base + lane x 16.
+    const bool more = it + 1 < nc && !(HH_ABLATE & 4096);
+    if (more) {
+      const size_t bn = (size_t)(cfirst + it + 1);
+      const char* const gsrc = reinterpret_cast<const char*>(a.eg + bn * a.kg * N);
+      char* const ldst = reinterpret_cast<char*>(eg + (size_t)((it & 1) ^ 1) * a.kg * N);
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int p0 = wave * 64; p0 < n_e4; p0 += K::THREADS)  // (a workgroup narrower than a wavefront: wave = 0)
+        if (p0 + lane < n_e4) lds_dma16(gsrc + (size_t)(p0 + lane) * 16, lds_offset_of(ldst + (size_t)p0 * 16));
+      if (wave == 0 && lane < N / 16)  // the groups' first table rows: N/4 ints
+        lds_dma16(reinterpret_cast<const char*>(a.cgs + bn * (N / 4)) + lane * 16,
+                  lds_offset_of(cgs + ((it & 1) ^ 1) * (N / 4)));
+    }
+    if (late && it > 0) part_b(it - 1);
+    part_a(it);
+    if (!late) part_b(it);
     // The LDS-DMA copies of the next candidate's factors count on vmcnt only; neither the workgroup-scope fence nor
     // s_barrier waits for them, so every wavefront retires its own copies before it arrives at the barrier.
     if (more) lds_dma_wait();
     __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
   }
+  if (late) part_b(nc - 1);
 }
 
 // ------------------------------------------------------------------------------------------
