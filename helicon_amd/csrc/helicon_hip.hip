@@ -1372,14 +1372,24 @@ struct FactorArgs {
   const double* units;
   const int* run_imax;    // [runs]
   float* eg;              // [B][kg][N] column factors: eg[k][x] = ex of table row cg(x/4) + k at column x
-  int* cgs;               // [B][N/4] first table row of every group of four columns
+  int* cgs;               // [B][N/4 + 4] first table row of every group of four columns, then the candidate's row count
   int run_len, kg, rows_lds;
   int count;              // candidates (0: nothing to do)
   DevGeom g;
 };
 
+// ints per candidate in the cgs array: the N/4 groups' first table rows, then (one 16-byte piece) the number of table
+// rows the candidate's build has to walk
 template <int N>
-__device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b) {
+__host__ __device__ constexpr int cgs_stride() { return N / 4 + 4; }
+
+// lds: workgroup scratch of at least (rows_lds + 1) floats — the axial coordinate of every table row of the candidate
+// (it depends on the row only, so its float64 product is done once per row, not once per row and column) and the
+// workgroup's row-count maximum.
+template <int N>
+__device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b, float* lds) {
+  float* const xc_tab = lds;                                   // [rows_lds]
+  int* const kc_s = reinterpret_cast<int*>(lds + a.rows_lds);  // max over the groups of (last - first + 1)
   const int x = threadIdx.x;
   const DevGeom& g = a.g;
   const Cand c = decode_candidate(a.params + 4 * (size_t)b, g);
@@ -1387,9 +1397,20 @@ __device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b) {
   const int rows = (2 * imax_t + 1) * g.n_units;
   const float rp = (float)g.rpx;
   const float k2 = g.inv_sigma2 * 1.44269504088896341f;
+  if (x == 0) *kc_s = 0;
+  for (int r = x; r < a.rows_lds; r += N) {
+    int i = r - imax_t, u = 0;
+    if (g.n_units > 1) {
+      i = r / g.n_units - imax_t;
+      u = r % g.n_units;
+    }
+    const bool ok = r < rows && i >= -c.imax && i <= c.imax;
+    // utils.py:160, float32 like the lattice list; rows the candidate does not have never pass the window test
+    xc_tab[r] = ok ? (float)a.units[3 * u + 2] + (float)((double)i * c.rise) : __builtin_nanf("");
+  }
   const int x0 = x & ~3;
   // first subunit index whose footprint can reach the group's columns (axial coordinate z_u + i rise;
-  // the slack covers |z_u| and the float32 roundings)
+  // the slack covers |z_u| and the float32 roundings): a conservative start, kg rows from it cover the group
   int cg = 0;
   if (c.M > 0) {
     const float lo = ((float)(x0 - N / 2) * g.apix - rp * g.apix - g.slack) / (float)c.rise;
@@ -1397,28 +1418,42 @@ __device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b) {
     cg = (min(i0, c.imax) + imax_t) * g.n_units;
   }
   cg = max(0, min(cg, a.rows_lds - a.kg));
+  __syncthreads();
+  // Tighten the window per group: rows [first, last] of the kg candidates that reach ANY of the group's four
+  // columns, by the SAME truncation test the raster and the run-table first pass apply.  The group's base moves to
+  // cg + first and the fused pass walks only max-over-groups(last - first + 1) rows of this candidate (rows past a
+  // group's own count carry zero factors, as before).
+  unsigned hit = 0;
   for (int k = 0; k < a.kg; ++k) {
-    const int r = cg + k;
-    int i = r - imax_t, u = 0;
-    if (g.n_units > 1) {
-      i = r / g.n_units - imax_t;
-      u = r % g.n_units;
-    }
+    const float cx = xc_tab[cg + k] * g.inv_apix + (float)(N / 2);
+    hit |= fabsf((float)x - cx) <= rp ? (1u << k) : 0u;
+  }
+  hit |= __shfl_xor((int)hit, 1, 64);
+  hit |= __shfl_xor((int)hit, 2, 64);
+  const int first = hit ? __ffs((int)hit) - 1 : 0;
+  const int count = hit ? (32 - __clz((int)hit)) - first : 0;
+  cg += first;
+  if ((x & 3) == 0 && count > 0) atomicMax(kc_s, count);
+  for (int k = 0; k < a.kg; ++k) {
     float wgt = 0.f;
-    if (r < rows && i >= -c.imax && i <= c.imax) {
-      const float xc = (float)a.units[3 * u + 2] + (float)((double)i * c.rise);  // utils.py:160, float32
+    if (k < count) {
+      const float xc = xc_tab[cg + k];
       const float cx = xc * g.inv_apix + (float)(N / 2);
       const float dx = (float)(x - N / 2) * g.apix - xc;
       if (fabsf((float)x - cx) <= rp) wgt = __builtin_amdgcn_exp2f(-dx * dx * k2);
     }
     a.eg[((size_t)b * a.kg + k) * N + x] = wgt;
   }
-  if ((x & 3) == 0) a.cgs[(size_t)b * (N / 4) + (x >> 2)] = cg;
+  int* const cgo = a.cgs + (size_t)b * cgs_stride<N>();
+  if ((x & 3) == 0) cgo[x >> 2] = cg;
+  __syncthreads();
+  if (x < 4) cgo[N / 4 + x] = *kc_s;
 }
 
 template <int N>
 __global__ __launch_bounds__(N) void k_column_factors(FactorArgs a) {
-  column_factors_of<N>(a, blockIdx.x);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];  // (rows_lds + 1) floats
+  column_factors_of<N>(a, blockIdx.x, reinterpret_cast<float*>(smem_f));
 }
 
 struct FusedArgs {
@@ -1427,7 +1462,7 @@ struct FusedArgs {
   const float2* table;    // [runs][cap][N/2]
   const int* run_imax;    // [runs]
   const float* eg;        // [B][kg][N]
-  const int* cgs;         // [B][N/4]
+  const int* cgs;         // [B][N/4 + 4]
   const float2* w2;
   double* partials;
   float* q_out;           // EPI_QSTORE
@@ -1473,7 +1508,7 @@ struct KF {
   static constexpr int BROW = N + 4;               // complex slots per panel row (+32 B against bank conflicts)
   static constexpr size_t LDS_BUF = (size_t)8 * BROW * sizeof(float2);
   static size_t lds(int rows_lds, int kg) {
-    return LDS_BUF + (size_t)8 * rows_lds * sizeof(float2) + 2 * ((size_t)kg * N * sizeof(float) + (size_t)(N / 4) * sizeof(int));
+    return LDS_BUF + (size_t)8 * rows_lds * sizeof(float2) + 2 * ((size_t)kg * N * sizeof(float) + (size_t)cgs_stride<N>() * sizeof(int));
   }
 };
 
@@ -1486,13 +1521,14 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   float2* const bufs = reinterpret_cast<float2*>(smem);
   float2* const gs = reinterpret_cast<float2*>(smem + K::LDS_BUF);                       // [8][rows_lds]
   float* const eg = reinterpret_cast<float*>(smem + K::LDS_BUF + (size_t)8 * a.rows_lds * sizeof(float2));  // [2][kg][N]
-  int* const cgs = reinterpret_cast<int*>(eg + (size_t)2 * a.kg * N);                    // [2][N/4]
+  int* const cgs = reinterpret_cast<int*>(eg + (size_t)2 * a.kg * N);                    // [2][N/4 + 4]
+  constexpr int CGS = cgs_stride<N>();
   const int tid = threadIdx.x;
   // leading grid layers: the next batch's column factors (so that batch needs no launch of its own),
   // then the scores of the previous batch
   if ((int)blockIdx.y < a.factor_layers) {
     const int cand = blockIdx.y * gridDim.x + blockIdx.x;
-    if (cand < a.next.count) column_factors_of<N>(a.next, cand);
+    if (cand < a.next.count) column_factors_of<N>(a.next, cand, reinterpret_cast<float*>(smem));  // these layers use no other LDS
     return;
   }
   if (a.fin.n > 0 && (int)blockIdx.y == a.factor_layers) {
@@ -1559,7 +1595,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   auto stage_factors = [&](int b) {
     const float4* const src = reinterpret_cast<const float4*>(a.eg + (size_t)b * a.kg * N);
     for (int e = tid; e < n_e4; e += K::THREADS) reinterpret_cast<float4*>(eg)[e] = src[e];
-    if (tid < N / 4) cgs[tid] = a.cgs[(size_t)b * (N / 4) + tid];
+    if (tid < CGS) cgs[tid] = a.cgs[(size_t)b * CGS + tid];
   };
   stage_factors(cfirst);  // buffer 0
   __syncthreads();
@@ -1581,7 +1617,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   auto part_a = [&](int cc) {
     const int cur = cc & 1;
     const float* const egc = eg + (size_t)cur * a.kg * N;
-    const int* const cgc = cgs + cur * (N / 4);
+    const int* const cgc = cgs + cur * CGS;
     // ---- this group's row of H, built by the group itself into its own exchange buffer (no workgroup barrier).
     // A lane owns two groups of four consecutive columns (x = 4 t + c and 4 (t + T) + c): two independent
     // accumulation chains, and the operands of the next table row are in flight while this row's FMAs issue.
@@ -1591,7 +1627,9 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       const float2* const grow1 = gs + gi * a.rows_lds + cgc[xg1];
       const float* const erow0 = egc + 4 * xg0;
       const float* const erow1 = egc + 4 * xg1;
-      const int kgn = (HH_ABLATE & 2048) ? 0 : a.kg;
+      // table rows this candidate needs (<= kg; a wave-uniform LDS word written by the factor kernel)
+      // (clamped to the buffer's kg: whatever the word holds, the walk is bounded)
+      const int kgn = (HH_ABLATE & 2048) ? 0 : max(0, min(a.kg, __builtin_amdgcn_readfirstlane(cgc[N / 4])));
       float2 p0 = make_float2(0.f, 0.f), p1 = p0, p2 = p0, p3 = p0, q0 = p0, q1 = p0, q2 = p0, q3 = p0;
       float2 ga = grow0[0], gb = grow1[0];
       float4 ea = *reinterpret_cast<const float4*>(erow0), eb = *reinterpret_cast<const float4*>(erow1);
@@ -1739,9 +1777,11 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       const int lane = tid & 63, wave = tid >> 6;
       for (int p0 = wave * 64; p0 < n_e4; p0 += K::THREADS)  // (a workgroup narrower than a wavefront: wave = 0)
         if (p0 + lane < n_e4) lds_dma16(gsrc + (size_t)(p0 + lane) * 16, lds_offset_of(ldst + (size_t)p0 * 16));
-      if (wave == 0 && lane < N / 16)  // the groups' first table rows: N/4 ints
-        lds_dma16(reinterpret_cast<const char*>(a.cgs + bn * (N / 4)) + lane * 16,
-                  lds_offset_of(cgs + ((it & 1) ^ 1) * (N / 4)));
+      // the groups' first table rows and the row count: N/4 + 4 ints = CGS / 4 pieces (65 at N = 1024: two wavefronts)
+      for (int p0 = wave * 64; p0 < CGS / 4; p0 += K::THREADS)
+        if (p0 + lane < CGS / 4)
+          lds_dma16(reinterpret_cast<const char*>(a.cgs + bn * CGS) + (size_t)(p0 + lane) * 16,
+                    lds_offset_of(reinterpret_cast<const char*>(cgs + ((it & 1) ^ 1) * CGS) + (size_t)p0 * 16));
     }
     if (late && it > 0) part_b(it - 1);
     part_a(it);
@@ -2610,7 +2650,7 @@ int launch_factors(hh_ctx* c, const FactorArgs& a, int batch) {
   ProfScope ps(c, 0);  // reported in the first-pass slot: it is what is left of the first pass
   FactorArgs args = a;
   args.count = batch;
-  hipLaunchKernelGGL((k_column_factors<N>), dim3(batch), dim3(N), 0, c->stream, args);
+  hipLaunchKernelGGL((k_column_factors<N>), dim3(batch), dim3(N), (size_t)(a.rows_lds + 1) * sizeof(float), c->stream, args);
   HH_HIP(c, hipGetLastError());
   return HH_OK;
 }
@@ -2696,7 +2736,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       if (c->d_cgs) HH_HIP(c, hipFree(c->d_cgs));
       c->d_cgs = nullptr;
       c->cap_cgs = 0;
-      HH_HIP(c, hipMalloc(&c->d_cgs, (size_t)2 * bmax * (c->n / 4) * sizeof(int)));
+      HH_HIP(c, hipMalloc(&c->d_cgs, (size_t)2 * bmax * (c->n / 4 + 4) * sizeof(int)));
       c->cap_cgs = (size_t)bmax;
     }
     const int rc = ensure_partials(c, bmax);
@@ -2732,7 +2772,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
     }
   }
   const size_t eg_half = (size_t)bmax * plan.kg * c->n;
-  const size_t cg_half = (size_t)bmax * (c->n / 4);
+  const size_t cg_half = (size_t)bmax * (c->n / 4 + 4);  // cgs_stride<N>()
   auto factor_args = [&](const Batch& bt, int half) {
     FactorArgs fa{};
     fa.params = d_params + 4 * bt.g0;
