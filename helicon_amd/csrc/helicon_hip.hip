@@ -42,7 +42,7 @@
 #define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads,
                            // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads; run-table first pass:
                            // 128 no stores, 256 no accumulation, 1024 no table staging; fused pass: 2048 no panel
-                           // accumulation, 4096 no column-factor prefetch (16 / 32 as for K_B)
+                           // accumulation, 4096 no column-factor prefetch (16 / 32 as for K_B), 8192 no second exchange
 #endif
 #ifndef HH_KA_WPS
 #define HH_KA_WPS 8        // K_A: waves per SIMD the register allocator must leave room for (4 workgroups per CU)
@@ -66,7 +66,7 @@
 #define HH_KT_KYW 128      // run-table first pass: ky rows per workgroup
 #endif
 #ifndef HH_KF_CPW
-#define HH_KF_CPW 64       // fused pass: candidates per workgroup (of one run) in large launches; 16 in small ones
+#define HH_KF_CPW 128      // fused pass: candidates per workgroup (of one run) in large launches; 16 in small ones
 #endif
 #ifndef HH_FUSED_BATCH
 #define HH_FUSED_BATCH 32768  // fused pass: candidates per launch (whole runs); 1.3 GB of column factors + moments at N = 512
@@ -88,6 +88,12 @@
 #endif
 #ifndef HH_KF_STAGGER
 #define HH_KF_STAGGER 1    // fused pass (N = 512): wavefronts 4-7 run half a candidate behind wavefronts 0-3
+#endif
+#ifndef HH_KF_CUT
+#define HH_KF_CUT 1        // fused pass: part A of a candidate ends after the butterflies of this transform stage
+#endif
+#ifndef HH_KF_PRIO
+#define HH_KF_PRIO 0       // fused pass: s_setprio level of the late wavefronts (0 = off)
 #endif
 #ifndef HH_XCD_MAP
 #define HH_XCD_MAP 1       // fused pass: all ky blocks of a layer of candidates on one XCD (shared L2)
@@ -285,6 +291,10 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
       char* const base = reinterpret_cast<char*>(buf);
 #pragma unroll
       for (int r = 0; r < R; ++r) *reinterpret_cast<float2*>(base + (bs ^ (unsigned)(r << 3))) = a[r];
+    } else if constexpr (SWZ2 && (HH_ABLATE & 8192) != 0) {
+      // timing-only: the second exchange costs nothing (values stay where they are)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = a[r];
     } else if constexpr (SWZ2) {
       const int j = t;  // NB == 1
       const int k = j & 7, b8 = ((j >> 3) & 1) * 8;
@@ -303,7 +313,8 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
   }  // PART != 2
   if constexpr (!LAST && PART != 1) {
     group_sync<T>();
-    if constexpr (SWZ2) {
+    if constexpr (SWZ2 && (HH_ABLATE & 8192) != 0) {
+    } else if constexpr (SWZ2) {
       if constexpr (T == 64) {  // (n >> 6) & 1 = m & 1
         const int e0 = t, e1 = t ^ 8;
 #pragma unroll
@@ -342,28 +353,32 @@ __device__ __forceinline__ void fft_stage(float2 (&v)[8], const TW& tw, int t, f
 // All T lanes of the transform must call it (group_sync inside; block-wide for T > 64).
 // SWZ1: xor-swizzle the first exchange (worth it where LDS time matters more than nine extra vector
 // instructions: the second pass and the fused pass; not in the raster + column-transform kernel).
-// fft_lanes in two halves: `first` runs the first stage's butterflies and leaves the data in the exchange buffer
-// (nothing of the transform lives in registers in between), `rest` picks it up there and finishes.
-template <int N, bool SWZ1 = false, typename TW>
-__device__ __forceinline__ void fft_lanes_first(float2 (&v)[8], const TW& tw, int t, float2* buf) {
-  fft_stage<N, Plan<N>::r0, 1, false, 0, 0, SWZ1, TW, 1>(v, tw, t, buf);
-}
-
-template <int N, bool SWZ1 = false, typename TW, bool RESUME = false>
-__device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
+// fft_lanes, optionally cut in two at the exchange after stage CUT (1-based): PHASE 1 runs the stages up to CUT's
+// butterflies and leaves the data in the exchange buffer (nothing of the transform lives in registers in between),
+// PHASE 2 picks it up there and finishes; PHASE 0 is the whole transform.
+template <int N, bool SWZ1, typename TW, int PHASE, int CUT>
+__device__ __forceinline__ void fft_lanes_part(float2 (&v)[8], const TW& tw, int t, float2* buf) {
   using P = Plan<N>;
   using W = TwN<N>;
-  fft_stage<N, P::r0, 1, false, 0, 0, SWZ1, TW, RESUME ? 2 : 0>(v, tw, t, buf);
-  if constexpr (P::n == 2) {
-    fft_stage<N, P::r1, P::r0, true, W::off1, W::lds1, false>(v, tw, t, buf);
-  } else if constexpr (P::n == 3) {
-    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, SWZ1>(v, tw, t, buf);
-    fft_stage<N, P::r2, P::r0 * P::r1, true, W::off2, W::lds2, false>(v, tw, t, buf);
-  } else {
-    fft_stage<N, P::r1, P::r0, false, W::off1, W::lds1, SWZ1>(v, tw, t, buf);
-    fft_stage<N, P::r2, P::r0 * P::r1, false, W::off2, W::lds2, false>(v, tw, t, buf);
-    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, W::off3, W::lds3, false>(v, tw, t, buf);
-  }
+  static_assert(CUT >= 1 && CUT < P::n, "the cut is at an exchange");
+  // part of stage s this call runs: 0 whole, 1 front, 2 back, -1 nothing
+  auto part = [](int s) constexpr {
+    if (PHASE == 0) return 0;
+    if (PHASE == 1) return s < CUT ? 0 : (s == CUT ? 1 : -1);
+    return s < CUT ? -1 : (s == CUT ? 2 : 0);
+  };
+  if constexpr (part(1) >= 0) fft_stage<N, P::r0, 1, false, 0, 0, SWZ1, TW, part(1)>(v, tw, t, buf);
+  if constexpr (part(2) >= 0)
+    fft_stage<N, P::r1, P::r0, P::n == 2, W::off1, W::lds1, SWZ1, TW, part(2)>(v, tw, t, buf);
+  if constexpr (P::n > 2 && part(3) >= 0)
+    fft_stage<N, P::r2, P::r0 * P::r1, P::n == 3, W::off2, W::lds2, false, TW, part(3)>(v, tw, t, buf);
+  if constexpr (P::n > 3 && part(4) >= 0)
+    fft_stage<N, P::r3, P::r0 * P::r1 * P::r2, true, W::off3, W::lds3, false, TW, part(4)>(v, tw, t, buf);
+}
+
+template <int N, bool SWZ1 = false, typename TW>
+__device__ __forceinline__ void fft_lanes(float2 (&v)[8], const TW& tw, int t, float2* buf) {
+  fft_lanes_part<N, SWZ1, TW, 0, 1>(v, tw, t, buf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1612,7 +1627,9 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   // registers between A and B, and the factor buffers are used exactly as without the stagger: A(it) reads buffer
   // it & 1 in round it, the copies for it + 1 go to the other buffer, one workgroup barrier closes the round.
   constexpr bool STAGGER = HH_KF_STAGGER && T == 64;
+  constexpr int KCUT = (HH_KF_CUT < Plan<N>::n) ? HH_KF_CUT : 1;  // A ends at the exchange after this stage
   const bool late = STAGGER && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4;
+  if (HH_KF_PRIO && late) __builtin_amdgcn_s_setprio(HH_KF_PRIO);
 
   auto part_a = [&](int cc) {
     const int cur = cc & 1;
@@ -1674,14 +1691,14 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       }
     }
     if constexpr (T > 64) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
-    if (!(HH_ABLATE & 16)) fft_lanes_first<N, HH_FFT_SWZ != 0>(v, twsrc, t, buf);
+    if (!(HH_ABLATE & 16)) fft_lanes_part<N, HH_FFT_SWZ != 0, TwRegs, 1, KCUT>(v, twsrc, t, buf);
   };
 
   auto part_b = [&](int cc) {
     const size_t b = (size_t)(cfirst + cc);
     float2 v[8];
     if (!(HH_ABLATE & 16)) {
-      fft_lanes<N, HH_FFT_SWZ != 0, TwRegs, true>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
+      fft_lanes_part<N, HH_FFT_SWZ != 0, TwRegs, 2, KCUT>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
     } else {
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
