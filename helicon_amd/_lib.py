@@ -55,6 +55,7 @@ EXPORTS = {
     "hh_abi_version": (C.c_int, []),
     "hh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "hh_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int]),
+    "hh_create2": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int, C.c_int]),
     "hh_destroy": (None, [_ctx]),
     "hh_max_batch": (C.c_int, [_ctx]),
     "hh_last_error": (C.c_char_p, [_ctx]),

@@ -2231,9 +2231,14 @@ struct EventPair {
 
 }  // namespace
 
+#include "general_sizes.inc"  // kernels of the general-size path (any ny x nx) and struct hh_gen
+
 struct hh_ctx {
   int device = 0;
-  int n = 0;
+  int n = 0;                     // side of a square power-of-two context; 0 for a general-size one
+  int ny = 0, nx = 0;            // image rows / columns (the helical axis runs along the columns)
+  bool general = false;          // true: every entry point goes through general_sizes.inc / general_host.inc
+  hh_gen* gen = nullptr;
   int max_batch = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -2294,6 +2299,9 @@ struct hh_ctx {
 };
 
 namespace {
+
+// general-size path (general_host.inc, included at the end of this namespace)
+int gen_sweep(hh_ctx* c, const double* d_params, const double* h_params, int64_t n_cand, float* d_scores, int64_t ld);
 
 int fail(hh_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg; else g_create_error = msg;
@@ -2927,6 +2935,7 @@ int sweep_transform(hh_ctx* c, const double* d_params, int64_t g, float* d_score
 // their `g` argument for that addressing, so they are handed ld.
 int sweep_on_device(hh_ctx* c, const double* d_params, const int64_t n_cand, float* d_scores,
                     const double* h_params = nullptr, int64_t ld = 0) {
+  if (c->general) return gen_sweep(c, d_params, h_params, n_cand, d_scores, ld);
   RunPlan plan = plan_runs(c, h_params, n_cand);
   c->last_first_pass = plan.ok ? (plan.fused ? 2 : 1) : 0;
   const int64_t g = ld > 0 ? ld : n_cand;
@@ -3040,6 +3049,8 @@ int cosine(hh_ctx* c, const T* a, const T* b, int64_t n, double* out) {
   return HH_OK;
 }
 
+#include "general_host.inc"  // host side of the general-size path
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -3064,10 +3075,15 @@ int64_t hh_algorithmic_bytes(int n) { return 4LL * n * n + 16LL * n * (n / 2 + 1
 
 const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int hh_create(hh_ctx** out, int device, int n, int max_batch) {
+int hh_create(hh_ctx** out, int device, int n, int max_batch) { return hh_create2(out, device, n, n, max_batch); }
+
+int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
   if (!out) return fail(nullptr, HH_ERR_ARG, "hh_create: out is NULL");
   *out = nullptr;
-  if (!supported_n(n)) return fail(nullptr, HH_ERR_ARG, "hh_create: image side must be a power of two in [32, 1024]");
+  const bool general = !(ny == nx && supported_n(ny));
+  const int n = general ? 0 : ny;
+  if (general && (ny < 8 || nx < 8 || ny > 1024 || nx > 1024))
+    return fail(nullptr, HH_ERR_ARG, "hh_create: image sides must lie in [8, 1024]");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, HH_ERR_HIP, "hh_create: no HIP device is visible (the sweep has no CPU fallback)");
@@ -3077,7 +3093,7 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
     return fail(nullptr, HH_ERR_HIP, "hh_create: hipGetDeviceProperties failed");
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(nullptr, HH_ERR_HIP, std::string("hh_create: built for gfx950 only, device is ") + prop.gcnArchName);
-  if (max_batch <= 0) {
+  if (max_batch <= 0 && !general) {
     // one batch of half spectra (N^2 * 4 B each) = 256 MiB, the size of the Infinity Cache:
     // measured best on MI355X (larger batches fall out of the cache, smaller ones leave CUs idle
     // at the tails of the two kernels)
@@ -3089,6 +3105,9 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   if (!c) return fail(nullptr, HH_ERR_NOMEM, "hh_create: out of host memory");
   c->device = device;
   c->n = n;
+  c->ny = ny;
+  c->nx = nx;
+  c->general = general;
   c->max_batch = max_batch;
   auto bail = [&](int code, const std::string& msg) {
     g_create_error = msg;
@@ -3103,6 +3122,14 @@ int hh_create(hh_ctx** out, int device, int n, int max_batch) {
   HH_CREATE_HIP(hipSetDevice(device));
   HH_CREATE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  if (general) {  // runtime-sized kernels; buffers grow with the sweeps
+    HH_CREATE_HIP(hipMalloc(&c->d_units, (size_t)HH_MAX_UNITS * 3 * sizeof(double)));
+    c->max_batch = (int)GEN_BATCH;
+    const int rcg = gen_create(c, ny, nx);
+    if (rcg) return bail(rcg, c->err);
+    *out = c;
+    return HH_OK;
+  }
   HH_CREATE_HIP(hipMalloc(&c->d_tw, (size_t)n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_inter, (size_t)max_batch * (n / 2) * n * sizeof(float2)));
   HH_CREATE_HIP(hipMalloc(&c->d_partials, (size_t)2 * max_batch * npart_for(n) * 3 * sizeof(double)));
@@ -3150,6 +3177,7 @@ void hh_destroy(hh_ctx* c) {
 
   (void)hipFree(c->d_spec);
   (void)hipFree(c->d_img);
+  gen_free(c);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -3184,13 +3212,13 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
   if (!(g->apix > 0) || !(g->ball_radius > 0) || !(g->helical_diameter >= 0))
     return fail(c, HH_ERR_ARG, "hh_set_geometry: apix and ball_radius must be positive");
   // utils.py:88
-  if (!(g->helical_diameter + g->ball_radius < c->n * g->apix * 0.99))
+  if (!(g->helical_diameter + g->ball_radius < c->ny * g->apix * 0.99))
     return fail(c, HH_ERR_ARG, "hh_set_geometry: helical_diameter + ball_radius must be < 0.99 * ny * apix");
   if (g->n_units < 0 || g->n_units > HH_MAX_UNITS) return fail(c, HH_ERR_ARG, "hh_set_geometry: n_units out of range");
   if (g->n_units > 1 && !g->units) return fail(c, HH_ERR_ARG, "hh_set_geometry: units is NULL");
   HH_HIP(c, hipSetDevice(c->device));
   DevGeom d{};
-  d.height = (double)c->n * g->apix;
+  d.height = (double)c->nx * g->apix;
   d.apix = (float)g->apix;
   d.inv_apix = (float)(1.0 / g->apix);
   const double sigma2 = g->ball_radius * g->ball_radius / std::log(2.0);
@@ -3200,7 +3228,7 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
   // exp(-(R*apix)^2 / sigma2) < 2^-bits
   d.rpx = (int)std::ceil(std::sqrt(sigma2 * bits * std::log(2.0)) / g->apix);
   if (d.rpx < 1) d.rpx = 1;
-  if (d.rpx > c->n) d.rpx = c->n;
+  if (d.rpx > std::max(c->ny, c->nx)) d.rpx = std::max(c->ny, c->nx);
   d.has_rot = (g->tilt != 0.0 || g->psi != 0.0) ? 1 : 0;
   {
     // R = Rx(-psi) * Ry(tilt) (scipy from_euler("yx", (tilt, -psi)), utils.py:167); rows 1, 2
@@ -3238,6 +3266,7 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
 int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8_t* mask, int log_flag) {
   if (!c || !images || !mask || n_segments <= 0) return fail(c, HH_ERR_ARG, "hh_set_reference: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
+  if (c->general) return gen_set_reference(c, images, n_segments, mask, log_flag);
   const int n = c->n;
   const size_t npix = (size_t)n * n, nh = (size_t)(n / 2 + 1) * n;
   int rc = ensure_img(c, n_segments);
@@ -3452,6 +3481,7 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
   if (rc) return rc;
   if (!params || !image_out) return fail(c, HH_ERR_ARG, "hh_simulate: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
+  if (c->general) return gen_simulate(c, params, image_out);
   const size_t npix = (size_t)c->n * c->n;
   rc = ensure_img(c, 1);
   if (rc) return rc;
@@ -3482,6 +3512,7 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
 int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_out, float* phase_out) {
   if (!c || !image || !pwr_out) return fail(c, HH_ERR_ARG, "hh_power_spectrum: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
+  if (c->general) return gen_power_spectrum(c, image, log_flag, pwr_out, phase_out);
   const int n = c->n;
   const size_t npix = (size_t)n * n;
   int rc = ensure_img(c, 3);  // [0] input, [1] pwr, [2] phase
@@ -3513,6 +3544,8 @@ int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_ou
 int hh_low_high_pass_filter(hh_ctx* c, const float* image, double low_pass_fraction, double high_pass_fraction,
                             float* out) {
   if (!c || !image || !out) return fail(c, HH_ERR_ARG, "hh_low_high_pass_filter: bad argument");
+  if (c->general)
+    return fail(c, HH_ERR_ARG, "hh_low_high_pass_filter: the device filter serves square power-of-two images only");
   HH_HIP(c, hipSetDevice(c->device));
   const int n = c->n;
   const size_t npix = (size_t)n * n, nh = (size_t)(n / 2 + 1) * n;
@@ -3657,6 +3690,7 @@ int hh_apply_helical_symmetry(int device, const float* data, const int32_t in_sh
 
 int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
   if (!c || bytes <= 0 || (mode != 0 && mode != 1)) return fail(c, HH_ERR_ARG, "hh_calibrate_traffic: bad argument");
+  if (c->general) return fail(c, HH_ERR_ARG, "hh_calibrate_traffic: square power-of-two contexts only");
   HH_HIP(c, hipSetDevice(c->device));
   const size_t unit = (size_t)256 * 512 * sizeof(float2);  // one 512-side half spectrum (1 MiB)
   const size_t n_units = std::max<size_t>(1, (size_t)bytes / unit);

@@ -39,7 +39,28 @@ __all__ = [
     "units_to_cylindrical",
 ]
 
-_SUPPORTED_N = (32, 64, 128, 256, 512, 1024)
+_SUPPORTED_N = (32, 64, 128, 256, 512, 1024)   # square sides served by the tuned kernels
+_MIN_SIDE, _MAX_SIDE = 8, 1024                    # every other (ny, nx) in this range: runtime-sized kernels
+
+
+def _largest_prime_factor(n: int) -> int:
+    p, m, best = 2, int(n), 1
+    while p * p <= m:
+        while m % p == 0:
+            best, m = p, m // p
+        p += 1
+    return max(best, m) if m > 1 else best
+
+
+def _image_shape(ny, nx) -> tuple[int, int]:
+    """Validate an image shape for the gfx950 path (``hh_create2``): sides in [8, 1024]; the row transform along
+    the helical axis handles radices 2, 3, 5 and primes up to 31."""
+    ny, nx = int(ny), int(nx)
+    if not (_MIN_SIDE <= ny <= _MAX_SIDE and _MIN_SIDE <= nx <= _MAX_SIDE):
+        raise ValueError(f"image sides must lie in [{_MIN_SIDE}, {_MAX_SIDE}]; got ({ny}, {nx})")
+    if not (ny == nx and ny in _SUPPORTED_N) and _largest_prime_factor(nx) > 31:
+        raise ValueError(f"nx = {nx} has a prime factor above 31; pad or crop the image along the helical axis")
+    return ny, nx
 
 
 def _f32(a):
@@ -68,15 +89,18 @@ class SweepEngine:
     reference calls its task function from pool threads (app.py:2473-2476), and two threads with
     different images must not interleave between ``set_reference`` and ``sweep``."""
 
-    def __init__(self, n: int, device: int = 0, max_batch: int = 0):
-        if n not in _SUPPORTED_N:
-            raise ValueError(f"image side must be one of {_SUPPORTED_N}, got {n}")
+    def __init__(self, n, device: int = 0, max_batch: int = 0):
+        """``n``: the side of a square image, or ``(ny, nx)``.  Square power-of-two sides 32...1024 run the tuned
+        kernels; any other shape the runtime-sized ones (same results, lower throughput; ``self.general``)."""
+        ny, nx = (n, n) if np.isscalar(n) else n
+        self.ny, self.nx = _image_shape(ny, nx)
+        self.n = self.ny if self.ny == self.nx else None
+        self.general = not (self.ny == self.nx and self.ny in _SUPPORTED_N)
         self._L = _lib.lib()
         self._ctx = C.c_void_p()
-        self.n = int(n)
         self.device = int(device)
         self._lock = threading.RLock()
-        _lib.check(self._L.hh_create(C.byref(self._ctx), self.device, self.n, int(max_batch)), None)
+        _lib.check(self._L.hh_create2(C.byref(self._ctx), self.device, self.ny, self.nx, int(max_batch)), None)
         self.max_batch = int(self._L.hh_max_batch(self._ctx))
         self.n_segments = 0
         self._geom_key = None
@@ -124,7 +148,7 @@ class SweepEngine:
         key = (float(apix), float(helical_diameter), float(ball_radius), float(tilt), float(psi), float(dy),
                None if units is None else np.asarray(units, dtype=np.float64).tobytes(), int(tail_bits))
         # the reference asserts (utils.py:88); keep its exception type
-        assert helical_diameter + ball_radius < self.n * apix * 0.99
+        assert helical_diameter + ball_radius < self.ny * apix * 0.99
         g = _lib.hh_geom()
         g.apix, g.helical_diameter, g.ball_radius = float(apix), float(helical_diameter), float(ball_radius)
         g.tilt, g.psi, g.dy = float(tilt), float(psi), float(dy)
@@ -154,13 +178,13 @@ class SweepEngine:
         imgs = _f32(images)
         if imgs.ndim == 2:
             imgs = imgs[None]
-        if imgs.ndim != 3 or imgs.shape[1:] != (self.n, self.n):
-            raise ValueError(f"images must be [S, {self.n}, {self.n}], got {imgs.shape}")
+        if imgs.ndim != 3 or imgs.shape[1:] != (self.ny, self.nx):
+            raise ValueError(f"images must be [S, {self.ny}, {self.nx}], got {imgs.shape}")
         if mask is None:
-            mask = radial_band_mask(self.n, self.n)
+            mask = radial_band_mask(self.ny, self.nx)
         m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
-        if m.shape != (self.n, self.n):
-            raise ValueError(f"mask must be [{self.n}, {self.n}] on the fftshifted plane")
+        if m.shape != (self.ny, self.nx):
+            raise ValueError(f"mask must be [{self.ny}, {self.nx}] on the fftshifted plane")
         with self._lock:
             try:
                 self._check(self._L.hh_set_reference(self._ctx, _ptr(imgs, C.c_float), imgs.shape[0],
@@ -242,17 +266,17 @@ class SweepEngine:
     # -- the primitives ---------------------------------------------------------------------
     def simulate(self, twist, rise, csym, rot=0.0) -> np.ndarray:
         p = np.array([twist, rise, csym, rot], dtype=np.float64)
-        out = np.empty((self.n, self.n), dtype=np.float32)
+        out = np.empty((self.ny, self.nx), dtype=np.float32)
         with self._lock:
             self._check(self._L.hh_simulate(self._ctx, _ptr(p, C.c_double), _ptr(out, C.c_float)))
         return out
 
     def power_spectrum(self, image, log=True, want_phase=True):
         img = _f32(image)
-        if img.shape != (self.n, self.n):
-            raise ValueError(f"image must be [{self.n}, {self.n}]")
-        pwr = np.empty((self.n, self.n), dtype=np.float32)
-        phase = np.empty((self.n, self.n), dtype=np.float32) if want_phase else None
+        if img.shape != (self.ny, self.nx):
+            raise ValueError(f"image must be [{self.ny}, {self.nx}]")
+        pwr = np.empty((self.ny, self.nx), dtype=np.float32)
+        phase = np.empty((self.ny, self.nx), dtype=np.float32) if want_phase else None
         with self._lock:
             self._check(self._L.hh_power_spectrum(self._ctx, _ptr(img, C.c_float), 1 if log else 0,
                                                   _ptr(pwr, C.c_float),
@@ -261,8 +285,10 @@ class SweepEngine:
 
     def low_high_pass_filter(self, image, low_pass_fraction=0.0, high_pass_fraction=0.0) -> np.ndarray:
         img = _f32(image)
-        if img.shape != (self.n, self.n):
-            raise ValueError(f"image must be [{self.n}, {self.n}]")
+        if self.general:
+            raise NotImplementedError("the device low/high-pass filter serves square power-of-two images")
+        if img.shape != (self.ny, self.nx):
+            raise ValueError(f"image must be [{self.ny}, {self.nx}]")
         out = np.empty_like(img)
         with self._lock:
             self._check(self._L.hh_low_high_pass_filter(self._ctx, _ptr(img, C.c_float), float(low_pass_fraction),
@@ -326,7 +352,7 @@ class SweepEngine:
             self._check(self._L.hh_calibrate_traffic(self._ctx, int(mode), int(nbytes)))
 
     def algorithmic_bytes(self) -> int:
-        return int(self._L.hh_algorithmic_bytes(self.n))
+        return 4 * self.ny * self.nx + 16 * self.nx * (self.ny // 2 + 1)  # = hh_algorithmic_bytes(n) for a square
 
 
 # ------------------------------------------------------------------------------------------
@@ -336,17 +362,19 @@ _engines: dict = {}
 _engines_lock = threading.Lock()
 
 
-def _engine(n: int, device: int = 0) -> SweepEngine:
+def _engine(shape, device: int = 0) -> SweepEngine:
+    shape = (int(shape), int(shape)) if np.isscalar(shape) else (int(shape[0]), int(shape[1]))
     with _engines_lock:
-        e = _engines.get((n, device))
+        e = _engines.get((shape, device))
         if e is None:
-            e = _engines[(n, device)] = SweepEngine(n, device)
+            e = _engines[(shape, device)] = SweepEngine(shape, device)
         return e
 
 
 def _square_side(ny, nx):
+    """Shape check of the entry points that need the tuned kernels (the Fourier filter)."""
     if ny != nx or ny not in _SUPPORTED_N:
-        raise ValueError(f"the gfx950 path handles square images with side in {_SUPPORTED_N}; got ({ny}, {nx})")
+        raise ValueError(f"this function handles square images with side in {_SUPPORTED_N}; got ({ny}, {nx})")
     return int(ny)
 
 
@@ -363,8 +391,7 @@ def simulate_helical_projection(n, twist, rise, csym, helical_diameter, ball_rad
     assert n >= 1
     if not rise > 0:
         raise ValueError("negative dimensions are not allowed")  # what np.zeros raises in the reference
-    side = _square_side(ny, nx)
-    eng = _engine(side, device)
+    eng = _engine(_image_shape(ny, nx), device)
     units = None
     if n > 1:  # the reference's three draws, in its order (utils.py:140-144); rot is added on the device
         r = np.sqrt(np.random.uniform(0, helical_diameter**2 / 4, n))
@@ -388,8 +415,7 @@ def compute_power_spectra(data, apix, cutoff_res=None, output_size=None, log=Tru
         raise NotImplementedError("Fourier-space zoom (cutoff_res) is outside the accelerated path")
     if output_size is not None and tuple(output_size) != tuple(data.shape):
         raise NotImplementedError("Fourier-space zoom (output_size) is outside the accelerated path")
-    side = _square_side(*data.shape)
-    eng = _engine(side, device)
+    eng = _engine(_image_shape(*data.shape), device)
     with eng.session():
         pwr, phase = eng.power_spectrum(data, log=log, want_phase=True)
         if 0 < low_pass_fraction < 1 or 0 < high_pass_fraction < 1:
@@ -495,9 +521,9 @@ def sweep(images, twists, rises, csyms=(1,), *, apix, helical_diameter, ball_rad
     """Score every (csym, twist, rise) candidate against the experimental image(s) on one GPU.
     For several GPUs see ``helicon_amd.distributed.sweep_distributed``."""
     imgs = np.asarray(images)
-    side = _square_side(*imgs.shape[-2:])
-    eng = engine or _engine(side, device)
-    grid = build_grid(twists, rises, csyms, tube_length=side * apix, rot=rot)
+    ny, nx = _image_shape(*imgs.shape[-2:])
+    eng = engine or _engine((ny, nx), device)
+    grid = build_grid(twists, rises, csyms, tube_length=nx * apix, rot=rot)
     from .distributed import harmless_rise
 
     params = grid.params.copy()
@@ -614,12 +640,11 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
             if len(_prepared) >= _PREPARED_MAX:
                 _prepared.pop(next(iter(_prepared)))
             _prepared[pkey] = prepared
-    ny, nx = prepared.shape
-    side = _square_side(ny, nx)
+    ny, nx = _image_shape(*prepared.shape)
     diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))
     ball_radius = float(opts.get("ball_radius", 2.0 * apix))
     rkey = (pkey, None if mask is None else _digest(np.asarray(mask) != 0), log)
-    eng = _engine(side, device)
+    eng = _engine((ny, nx), device)
     with eng.session():
         eng.set_geometry(apix=apix, helical_diameter=diameter, ball_radius=ball_radius, tilt=tilt, psi=psi, dy=dy)
         eng.set_reference(prepared, mask, log=log, key=rkey)

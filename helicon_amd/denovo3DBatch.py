@@ -9,8 +9,9 @@ descending, app.py:2521-2523) this driver reproduces without the Shiny UI.
     python -m helicon_amd.denovo3DBatch image.npy --apix 2.0 --twist 25 33 0.2 --rise 8 13 0.2 \\
            --csym 1 --out scores.npz [--mask mask.npy] [--no-log] [--device 0] [--top 10]
 
-Images are ``.npy`` arrays or MRC files/stacks (``[N, N]`` or ``[S, N, N]``; square, side a power of two
-in 32…1024); ``--index`` picks slices of a stack like ``read_image_2d`` (io_mrc.py:71-100).
+Images are ``.npy`` arrays or MRC files/stacks (``[ny, nx]`` or ``[S, ny, nx]``, helical axis along x; square
+power-of-two sides 32…1024 run the tuned kernels, any other size in 8…1024 the runtime-sized ones); ``--index``
+picks slices of a stack like ``read_image_2d`` (io_mrc.py:71-100).
 """
 from __future__ import annotations
 
@@ -31,7 +32,7 @@ def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
     parser.add_argument("--twist", type=float, nargs=3, metavar=("MIN", "MAX", "STEP"), required=True)
     parser.add_argument("--rise", type=float, nargs=3, metavar=("MIN", "MAX", "STEP"), required=True)
     parser.add_argument("--csym", type=int, nargs="+", default=[1])
-    parser.add_argument("--helical-diameter", type=float, default=None, help="Angstrom (default 0.4 * N * apix)")
+    parser.add_argument("--helical-diameter", type=float, default=None, help="Angstrom (default 0.4 * ny * apix)")
     parser.add_argument("--ball-radius", type=float, default=None, help="Angstrom (default 2 * apix)")
     parser.add_argument("--rot", type=float, default=0.0)
     parser.add_argument("--tilt", type=float, default=0.0)
@@ -61,7 +62,7 @@ def run(args) -> dict:
     if args.index:
         images = images[np.asarray(args.index)]
     images = np.ascontiguousarray(images, dtype=np.float32)
-    n = images.shape[-1]
+    n = images.shape[-2]  # rows: the lattice has to fit across the helical axis (utils.py:88)
     twists = sweep_axis(*args.twist)
     rises = sweep_axis(*args.rise)
     mask = np.load(args.mask) if args.mask else None

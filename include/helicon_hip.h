@@ -19,8 +19,9 @@
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative hh_status otherwise, with a message available from hh_last_error(); nothing calls
- * exit(); no host pointer is retained after a call returns.  Images are square, side N a power
- * of two in [32, 1024], C-order float32 with the helical axis along the columns (x).
+ * exit(); no host pointer is retained after a call returns.  Images are C-order float32, ny x nx, with the
+ * helical axis along the columns (x); "N" below is the side of a square power-of-two image (the tuned kernels),
+ * general sizes: hh_create2.
  * A context is bound to one device and is NOT thread-safe (serialise calls per context).
  */
 #ifndef HELICON_HIP_H
@@ -85,8 +86,14 @@ typedef struct hh_profile {
 int hh_abi_version(void);
 int hh_device_count(int* count);
 
-/* device: HIP ordinal; n: image side; max_batch: candidates per launch (0 = default). */
+/* device: HIP ordinal; n: image side; max_batch: candidates per launch (0 = default).
+ * hh_create2 takes the image's rows and columns (utils.py:31-47 and transforms.py:687-704 accept any (ny, nx); the
+ * helical axis runs along the columns).  Square power-of-two sides 32 ... 1024 get the tuned kernels (hh_create(n) is
+ * hh_create2(n, n)); every other size in [8, 1024]^2 whose nx has no prime factor above 31 is served by runtime-sized
+ * kernels with the same semantics: hh_simulate, hh_power_spectrum, hh_set_reference and the sweeps (candidate lists
+ * are swept run by run; tilt = psi = 0), not hh_low_high_pass_filter. */
 int hh_create(hh_ctx** out, int device, int n, int max_batch);
+int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch);
 void hh_destroy(hh_ctx* ctx);
 /* candidates per kernel launch this context was created with (the resolved default). */
 int hh_max_batch(const hh_ctx* ctx);

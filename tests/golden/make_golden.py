@@ -131,6 +131,50 @@ def g3_composed():
     np.savez_compressed(OUT / "g3_composed.npz", **arrs)
 
 
+def g3b_general_sizes():
+    """The same composition on image sizes that are neither square nor powers of two (utils.py:31-47 and
+    transforms.py:687-704 take any (ny, nx)): scores of a small twist-major grid, both log settings, and one
+    simulated projection per size.  Sizes: 96 x 96 (2^5 3), 80 x 120 (ny != nx), 50 x 70 (factors 5 and 7),
+    45 x 63 (odd sides)."""
+    arrs = {}
+    tags = []
+    for ny, nx, apix, truth, twists, rises in (
+        (96, 96, 2.0, (29.0, 10.0, 1), np.arange(26.0, 32.0 + 0.5, 1.0), np.arange(8.0, 12.0 + 0.25, 0.5)),
+        (80, 120, 2.0, (-40.0, 7.0, 2), np.arange(-43.0, -37.0 + 0.5, 1.0), np.arange(5.0, 9.0 + 0.25, 0.5)),
+        (50, 70, 3.0, (29.0, 12.0, 1), np.arange(27.0, 31.0 + 0.5, 1.0), np.arange(9.0, 15.0 + 0.25, 0.75)),
+        (45, 63, 3.0, (55.0, 9.0, 3), np.arange(52.0, 58.0 + 0.5, 1.0), np.arange(7.0, 11.0 + 0.25, 0.5)),
+    ):
+        tw0, rs0, cs0 = truth
+        d = 0.4 * ny * apix
+        br = 2 * apix
+        clean = utils.simulate_helical_projection(1, tw0, rs0, cs0, d, br, 0, 0, ny, nx, apix)
+        noise = np.random.default_rng(1).normal(0, 0.5 * clean.std(), clean.shape)
+        img = (clean + noise).astype(np.float32)
+        ky = np.arange(ny) - ny // 2
+        kx = np.arange(nx) - nx // 2
+        r2 = ky[:, None].astype(np.float64) ** 2 + kx[None, :].astype(np.float64) ** 2
+        mask = (r2 > 4.0) & (r2 < (min(ny, nx) // 2 - 1) ** 2)
+        tag = f"s{ny}x{nx}"
+        tags.append(tag)
+        arrs[f"{tag}_clean"] = clean.astype(np.float32)  # reference output, stored in float32 (tolerance of its test: 5e-6)
+        arrs[f"{tag}_image"] = img
+        arrs[f"{tag}_meta"] = np.asarray([ny, nx, apix, tw0, rs0, cs0, d, br], dtype=np.float64)
+        arrs[f"{tag}_twists"] = twists
+        arrs[f"{tag}_rises"] = rises
+        for log in (True, False):
+            pe = _pwr(img.astype(np.float64), log)
+            sc = np.zeros((len(twists), len(rises)))
+            for i, tw in enumerate(twists):
+                for j, rs in enumerate(rises):
+                    sim = utils.simulate_helical_projection(1, float(tw), float(rs), cs0, d, br, 0, 0, ny, nx, apix)
+                    sc[i, j] = analysis.cross_correlation_coefficient(pe[mask], _pwr(sim, log)[mask])
+            arrs[f"{tag}_scores_log{int(log)}"] = sc
+            arrs[f"{tag}_argmax_log{int(log)}"] = np.asarray(np.unravel_index(np.argmax(sc), sc.shape))
+        arrs[f"{tag}_pwr_log1"] = _pwr(img.astype(np.float64), True).astype(np.float32)
+    arrs["tags"] = np.asarray(tags)
+    np.savez_compressed(OUT / "g3b_general_sizes.npz", **arrs)
+
+
 def g6_filters():
     rng = np.random.default_rng(6)
     x = rng.normal(size=(32, 32))
@@ -189,6 +233,7 @@ if __name__ == "__main__":
     g1_simulate()
     g2_scores()
     g3_composed()
+    g3b_general_sizes()
     g6_filters()
     g7_helical_sym()
     (OUT / "VERSIONS.json").write_text(json.dumps(versions(), indent=1) + "\n")
