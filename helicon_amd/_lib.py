@@ -73,6 +73,10 @@ EXPORTS = {
     "hh_threshold_data": (C.c_int, [_ctx, _f32p, C.c_int64, C.c_int, C.c_double, _f32p]),
     "hh_argmax": (C.c_int, [_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     "hh_argmax_device": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
+    "hh_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "hh_comm_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
+    "hh_allgather": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hh_comm_destroy": (C.c_int, [_ctx]),
     "hh_simulate": (C.c_int, [_ctx, _f64p, _f32p]),
     "hh_power_spectrum": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),
     "hh_cross_correlation": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f64p]),

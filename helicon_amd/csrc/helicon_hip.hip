@@ -25,6 +25,7 @@
 // Everything is wave64 code: an N-point FFT is owned by N/8 lanes holding 8 points each
 // (one wavefront for N = 512), Stockham radix-8/4/2 stages exchange through LDS.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -2238,6 +2239,7 @@ struct hh_ctx {
   int n = 0;                     // side of a square power-of-two context; 0 for a general-size one
   int ny = 0, nx = 0;            // image rows / columns (the helical axis runs along the columns)
   bool general = false;          // true: every entry point goes through general_sizes.inc / general_host.inc
+  void* comm = nullptr;          // ncclComm_t of hh_comm_init (RCCL, loaded on first use)
   hh_gen* gen = nullptr;
   int max_batch = 0;
   hipStream_t own_stream = nullptr;
@@ -3150,6 +3152,7 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
 
 void hh_destroy(hh_ctx* c) {
   if (!c) return;
+  (void)hh_comm_destroy(c);
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& e : c->events) {
@@ -3473,6 +3476,94 @@ int hh_argmax_device(hh_ctx* c, const float* d_scores, int64_t n_rows, int64_t n
     HH_HIP(c, hipMemcpyAsync(h_index, d_index, (size_t)n_rows * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HH_HIP(c, hipStreamSynchronize(c->stream));
   }
+  return HH_OK;
+}
+
+// ---- the one collective of a multi-GPU sweep, without a host framework: RCCL through dlopen --------------------
+namespace {
+struct Rccl {
+  struct UniqueId { char b[128]; };  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl(std::string& err) {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    // the soname first: a process that already holds RCCL (torch.distributed's "nccl" backend) gets that same copy
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if ((r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (r.lib) {
+      r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+      r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+      r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+      r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    }
+  }
+  if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) {
+    err = "librccl.so.1 is not loadable (the multi-GPU entry points need RCCL)";
+    return nullptr;
+  }
+  return &r;
+}
+}  // namespace
+
+int hh_comm_unique_id(void* id128) {
+  if (!id128) return fail(nullptr, HH_ERR_ARG, "hh_comm_unique_id: NULL");
+  std::string err;
+  Rccl* r = rccl(err);
+  if (!r) return fail(nullptr, HH_ERR_STATE, err);
+  const int rc = r->GetUniqueId(id128);
+  if (rc) return fail(nullptr, HH_ERR_HIP, std::string("ncclGetUniqueId: ") + (r->GetErrorString ? r->GetErrorString(rc) : "?"));
+  return HH_OK;
+}
+
+int hh_comm_init(hh_ctx* c, int rank, int world, const void* id128) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(c, HH_ERR_ARG, "hh_comm_init: bad argument");
+  if (c->comm) return fail(c, HH_ERR_STATE, "hh_comm_init: the context already has a communicator");
+  std::string err;
+  Rccl* r = rccl(err);
+  if (!r) return fail(c, HH_ERR_STATE, err);
+  HH_HIP(c, hipSetDevice(c->device));
+  Rccl::UniqueId id;
+  std::memcpy(id.b, id128, sizeof(id.b));
+  const int rc = r->CommInitRank(&c->comm, world, id, rank);
+  if (rc) {
+    c->comm = nullptr;
+    return fail(c, HH_ERR_HIP, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "?"));
+  }
+  return HH_OK;
+}
+
+int hh_allgather(hh_ctx* c, const float* d_send, int64_t count, float* d_recv) {
+  if (!c || !d_send || !d_recv || count <= 0) return fail(c, HH_ERR_ARG, "hh_allgather: bad argument");
+  if (!c->comm) return fail(c, HH_ERR_STATE, "hh_allgather: hh_comm_init has not been called");
+  std::string err;
+  Rccl* r = rccl(err);
+  if (!r) return fail(c, HH_ERR_STATE, err);
+  HH_HIP(c, hipSetDevice(c->device));
+  const int rc = r->AllGather(d_send, d_recv, (size_t)count, /* ncclFloat32 */ 7, c->comm, c->stream);
+  if (rc) return fail(c, HH_ERR_HIP, std::string("ncclAllGather: ") + (r->GetErrorString ? r->GetErrorString(rc) : "?"));
+  return HH_OK;
+}
+
+int hh_comm_destroy(hh_ctx* c) {
+  if (!c) return HH_ERR_ARG;
+  if (!c->comm) return HH_OK;
+  std::string err;
+  Rccl* r = rccl(err);
+  if (r) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)r->CommDestroy(c->comm);
+  }
+  c->comm = nullptr;
   return HH_OK;
 }
 

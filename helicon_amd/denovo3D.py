@@ -245,6 +245,31 @@ class SweepEngine:
                                                  None, _ptr(out, C.c_int64)))
         return out
 
+    # -- the collective of a multi-GPU sweep through the C ABI (RCCL; no torch.distributed needed) ------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes made by ONE rank and handed to all others (file, socket, MPI ...): ``hh_comm_unique_id``."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().hh_comm_unique_id(buf), None)
+        return bytes(buf.raw)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        buf = C.create_string_buffer(unique_id, 128)
+        with self._lock:
+            self._check(self._L.hh_comm_init(self._ctx, int(rank), int(world), buf))
+
+    def allgather(self, d_send: int, count: int, d_recv: int):
+        """``count`` floats of every rank, rank-major, into ``d_recv`` (device pointers); queued on the engine's
+        stream behind the sweep that wrote ``d_send``."""
+        with self._lock:
+            self._check(self._L.hh_allgather(self._ctx, C.c_void_p(d_send), int(count), C.c_void_p(d_recv)))
+
+    def comm_destroy(self):
+        with self._lock:
+            self._check(self._L.hh_comm_destroy(self._ctx))
+
     def set_table_path(self, mode=2):
         """How runs of candidates that share (twist, csym, rot) are swept: 0 / False = like any other
         list (raster + two transforms per candidate), 1 = run tables + second pass, 2 / True = the

@@ -168,6 +168,21 @@ int hh_argmax(const float* scores, int64_t n, int64_t* index);
 int hh_argmax_device(hh_ctx* ctx, const float* d_scores, int64_t n_rows, int64_t n, int64_t ld, int64_t* d_index,
                      int64_t* h_index);
 
+/* The multi-GPU sweep's only collective for a caller without a host framework (the
+ * reference has no distributed code, its candidates are pool tasks: app.py:2473-2476).  One process per GPU, one
+ * context each.  RCCL is loaded with dlopen("librccl.so.1") on first use, so a single-GPU user never needs it.
+ *   hh_comm_unique_id   rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by any means;
+ *   hh_comm_init        every rank, collectively: a communicator of `world` ranks bound to this context;
+ *   hh_allgather        every rank contributes `count` floats from d_send; d_recv receives world x count floats in
+ *                       rank order; enqueued on the context's stream, i.e. ordered behind the sweep that produced
+ *                       d_send (hh_sweep_device_strided into a NaN-padded buffer: helicon_amd/distributed.py is the
+ *                       same step with torch.distributed) and ahead of hh_argmax_device on d_recv;
+ *   hh_comm_destroy     also done by hh_destroy. */
+int hh_comm_unique_id(void* id128);
+int hh_comm_init(hh_ctx* ctx, int rank, int world, const void* id128);
+int hh_allgather(hh_ctx* ctx, const float* d_send, int64_t count, float* d_recv);
+int hh_comm_destroy(hh_ctx* ctx);
+
 /* One simulated projection (host, N x N float32) for params[4] = (twist, rise, csym, rot). */
 int hh_simulate(hh_ctx* ctx, const double* params, float* image_out);
 

@@ -230,3 +230,36 @@ def test_compute_power_spectra_with_low_and_high_pass(n, lp, hp):
     got, _ = H.compute_power_spectra(img, 2.0, low_pass_fraction=lp, high_pass_fraction=hp)
     ref, _ = O.compute_power_spectra(img.astype(np.float64), 2.0, low_pass_fraction=lp, high_pass_fraction=hp)
     np.testing.assert_allclose(got, ref, rtol=0, atol=5e-5)
+
+
+# ---------------------------------------------------------------------------- the collective through the C ABI
+def test_c_abi_allgather_single_rank_rccl():
+    """hh_comm_unique_id / hh_comm_init / hh_allgather / hh_argmax_device: the sweep -> all-gather -> arg-max step
+    of a multi-GPU run with no host framework in the data path (world size 1 here; torch only allocates)."""
+    import torch
+
+    n, apix = 64, 2.0
+    d, br = 0.4 * n * apix, 2 * apix
+    clean = O.simulate_helical_projection(1, 29.0, 10.0, 1, d, br, 0, 0, n, n, apix)
+    imgs = np.stack([(clean + np.random.default_rng(s).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
+                     for s in range(2)])
+    grid = build_grid(np.arange(25.0, 33.5, 1.0), np.arange(8.0, 12.5, 0.5), (1,), tube_length=n * apix)
+    g, per = len(grid), len(grid) + 7                                   # a padded send buffer, like a short shard's
+    with H.SweepEngine(n) as eng:
+        eng.set_geometry(apix=apix, helical_diameter=d, ball_radius=br)
+        eng.set_reference(imgs)
+        ref = eng.sweep(grid.params)
+        eng.comm_init(0, 1, H.SweepEngine.comm_unique_id())
+        dp = torch.from_numpy(grid.params).cuda()
+        send = torch.full((2, per), float("nan"), dtype=torch.float32, device="cuda")
+        recv = torch.zeros((1, 2, per), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.sweep_device(dp.data_ptr(), g, send.data_ptr(), host_params=grid.params, ld_scores=per)
+        eng.allgather(send.data_ptr(), 2 * per, recv.data_ptr())
+        best = eng.argmax_device(recv.data_ptr(), 2, per, per)
+        eng.synchronize()
+        got = recv.cpu().numpy()[0]
+        eng.comm_destroy()
+    np.testing.assert_array_equal(got[:, :g], ref)
+    assert np.isnan(got[:, g:]).all()
+    assert best.tolist() == np.argmax(ref, axis=1).tolist()

@@ -14,7 +14,7 @@ import helicon_amd as H  # noqa: E402
 def make(n, n_seg, truth=(1.20, 4.75, 1), mask=None):
     eng = H.SweepEngine(n)
     apix = 1.0
-    eng.set_geometry(apix=apix, helical_diameter=0.4 * n * apix, ball_radius=2 * apix)
+    eng.set_geometry(apix=apix, helical_diameter=0.4 * eng.ny * apix, ball_radius=2 * apix)
     clean = eng.simulate(*truth)
     imgs = np.stack([(clean + np.random.default_rng(s).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
                      for s in range(n_seg)])
@@ -36,7 +36,7 @@ def run(name, eng, grid, reps=2):
 
 
 tw, rs = H.sweep_axis(0.01, 4.00, 0.01), H.sweep_axis(4.000, 5.245, 0.005)
-which = sys.argv[1:] or ["C3", "C4", "C5", "LOWRES"]
+which = sys.argv[1:] or ["C3", "C4", "C5", "LOWRES", "GEN"]
 if "C3" in which:
     run("C3 512^2, 400x250 grid x Csym 1..6", make(512, 1), H.build_grid(tw, rs, (1, 2, 3, 4, 5, 6), tube_length=512.0), reps=1)
 if "C4" in which:
@@ -48,3 +48,7 @@ if "C5" in which:
 if "LOWRES" in which:  # resolution-limited mask: only ky blocks below the cut-off are stored / read
     run("C2 grid, 512^2, mask 2 < r < 100 (13 of 32 ky blocks)", make(512, 1, mask=H.radial_band_mask(512, 512, 2, 100)),
         H.build_grid(tw, rs, (1,), tube_length=512.0))
+if "GEN" in which:  # sizes that are not powers of two: the runtime-sized kernels (hh_create2)
+    for shape, nt in (((200, 200), 200), ((400, 400), 100), ((300, 480), 100)):
+        run(f"general {shape[0]}x{shape[1]}, {nt}x250 grid", make(shape, 1),
+            H.build_grid(tw[:nt], rs, (1,), tube_length=float(shape[1])), reps=1)
