@@ -7,5 +7,6 @@ from .denovo3D import (SweepEngine, SweepResult, apply_helical_symmetry, compute
                        cross_correlation_coefficient, low_high_pass_filter, process_one_task,
                        simulate_helical_projection, sweep, threshold_data)
 from ._lib import HeliconHipError
+from .solver import lsq_reconstruct
 
 __version__ = "0.1.0"

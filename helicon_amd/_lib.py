@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-__all__ = ["HeliconHipError", "lib", "lib_path", "hh_geom", "hh_profile", "check", "EXPORTS"]
+__all__ = ["HeliconHipError", "lib", "lib_path", "hh_geom", "hh_profile", "hh_pa_params", "check", "EXPORTS"]
 
 _HERE = Path(__file__).resolve().parent
 
@@ -43,6 +43,18 @@ class hh_profile(C.Structure):
         ("n_finalize", C.c_int64),
         ("n_centres", C.c_int64),
         ("candidates", C.c_int64),
+    ]
+
+
+class hh_pa_params(C.Structure):
+    _fields_ = [
+        ("scale2d_to_3d", C.c_double), ("twist_degree", C.c_double), ("rise_pixel", C.c_double),
+        ("csym", C.c_int32),
+        ("tilt_degree", C.c_double), ("psi_degree", C.c_double), ("dy_pixel", C.c_double),
+        ("reconstruct_diameter_2d_pixel", C.c_int32), ("reconstruct_length_2d_pixel", C.c_int32),
+        ("reconstruct_diameter_3d_pixel", C.c_int32), ("reconstruct_diameter_3d_inner_pixel", C.c_int32),
+        ("reconstruct_length_3d_pixel", C.c_int32),
+        ("min_projection_lines", C.c_int64), ("min_sym_pairs", C.c_int64),
     ]
 
 
@@ -92,6 +104,16 @@ EXPORTS = {
     "hh_profile_get": (C.c_int, [_ctx, C.POINTER(hh_profile)]),
     "hh_calibrate_traffic": (C.c_int, [_ctx, C.c_int, C.c_int64]),
     "hh_algorithmic_bytes": (C.c_int64, [C.c_int]),
+    # Path A slice (helicon_amd/solver.py)
+    "hh_pa_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(hh_pa_params)]),
+    "hh_pa_destroy": (None, [C.c_void_p]),
+    "hh_pa_last_error": (C.c_char_p, [C.c_void_p]),
+    "hh_pa_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "hh_pa_get_rhs": (C.c_int, [C.c_void_p, _f32p, C.POINTER(C.c_int32)]),
+    "hh_pa_matvec": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, _f64p]),
+    "hh_pa_rmatvec": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, _f64p]),
+    "hh_pa_lsmr": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_int, _f64p,
+                             C.POINTER(C.c_int), _f64p]),
 }
 
 _lib = None

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -2233,6 +2234,7 @@ struct EventPair {
 }  // namespace
 
 #include "general_sizes.inc"  // kernels of the general-size path (any ny x nx) and struct hh_gen
+#include "path_a.inc"         // Path A (sparse least-squares scorer): projector kernels and struct hh_pa
 
 struct hh_ctx {
   int device = 0;
@@ -3841,3 +3843,5 @@ int hh_profile_get(hh_ctx* c, hh_profile* out) {
 }
 
 }  // extern "C"
+
+#include "path_a_host.inc"  // Path A: host side and C ABI (hh_pa_*)

@@ -1,0 +1,383 @@
+"""Path A on the GPU, first slice: ``lsq_reconstruct`` with the reference's signature
+(src/helicon/webApps/denovo3D/solver_linear_regression.py:31-56) for ``interpolation="nn"`` and
+``algorithm=dict(model="lsq")`` — the one deterministic configuration of the reference's scorer.
+
+What runs where:
+
+* libhelicon_hip.so (``hh_pa_*``, csrc/path_a.inc): the implicit system — the voxel index of every projection-ray sample
+  under every symmetry operation (the reference's ``build_A_data_matrix``, its dominant cost, never materialised as a
+  matrix), the symmetry-constraint pairs (``build_A_helical_sym_matrix``), ``A x`` / ``A^T y`` and the whole LSMR
+  iteration with its vectors on the device;
+* this module: what ``scipy.optimize.lsq_linear(method="trf", lsq_solver="lsmr")`` does around those LSMR solves when
+  the solution is bounded (solver_linear_regression.py:245-269: ``lb = 0, ub = max(b)`` under the positivity rule of
+  :352-355) — the trust-region-reflective iteration of scipy/optimize/_lsq/trf_linear.py, O(n) vector arithmetic per
+  outer iteration — plus the cosine score (:484-530) and the volume assembly (:532-547).
+
+Not in this slice (``NotImplementedError``): linear interpolation, the scikit-learn models, half-set solves
+(``fsc_test``), tilt/psi/dy refinement, scores other than cosine.  There is no CPU fallback: without the library or a
+GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["lsq_reconstruct", "PathAProblem", "get_cylindrical_mask", "cosine_similarity"]
+
+EPS = np.finfo(float).eps
+
+
+hh_pa_params = _lib.hh_pa_params
+_f64p = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_f64p)
+
+
+def get_cylindrical_mask(nz, ny, nx, rmin=0, rmax=-1, return_xyz=False):
+    """lib/analysis.py:731-774 (host-side helper: the order of the unknowns is the C-order rank of this mask)."""
+    k = np.arange(0, nz, dtype=np.int32) - nz // 2
+    j = np.arange(0, ny, dtype=np.int32) - ny // 2
+    i = np.arange(0, nx, dtype=np.int32) - nx // 2
+    Z, Y, X = np.meshgrid(k, j, i, indexing="ij")
+    if rmax < 0:
+        rmax = ny // 2 - 1
+    mask = X * X + Y * Y < rmax * rmax
+    if 0 < rmin < rmax:
+        mask &= X * X + Y * Y >= rmin * rmin
+    return (mask, (Z, Y, X)) if return_xyz else mask
+
+
+def cosine_similarity(a, b):
+    """lib/analysis.py:802-821 on host vectors (the prediction A_data x comes back from the device)."""
+    norm = np.linalg.norm(a) * np.linalg.norm(b)
+    return 0 if norm == 0 else np.sum(a * b) / norm
+
+
+class PathAProblem:
+    """One candidate's implicit least-squares system on the device (``hh_pa``)."""
+
+    def __init__(self, image, *, scale2d_to_3d, twist_degree, rise_pixel, csym, tilt_degree, psi_degree, dy_pixel,
+                 reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, reconstruct_diameter_3d_pixel,
+                 reconstruct_diameter_3d_inner_pixel, reconstruct_length_3d_pixel, min_projection_lines, min_sym_pairs,
+                 device=0):
+        self._L = _lib.lib()
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        if img.ndim != 2:
+            raise ValueError("projection_image must be 2-D")
+        q = hh_pa_params(float(scale2d_to_3d), float(twist_degree), float(rise_pixel), int(csym), float(tilt_degree),
+                         float(psi_degree), float(dy_pixel), int(reconstruct_diameter_2d_pixel),
+                         int(reconstruct_length_2d_pixel), int(reconstruct_diameter_3d_pixel),
+                         int(reconstruct_diameter_3d_inner_pixel), int(reconstruct_length_3d_pixel),
+                         int(min_projection_lines), int(min_sym_pairs))
+        self._h = C.c_void_p()
+        rc = self._L.hh_pa_create(C.byref(self._h), int(device), img.ctypes.data_as(C.POINTER(C.c_float)), img.shape[0],
+                                  img.shape[1], C.byref(q))
+        if rc:
+            msg = self._L.hh_pa_last_error(None)
+            kind = ValueError if rc == -1 else _lib.HeliconHipError
+            raise kind(f"hh_pa_create error {rc}: {msg.decode() if msg else '?'}")
+        dims = (C.c_int64 * 4)()
+        self._L.hh_pa_dims(self._h, dims)
+        self.n, self.m_data, self.m_sym, self.n_ops = (int(v) for v in dims)
+        self.m = self.m_data + self.m_sym
+        self.b_data = np.empty(self.m_data, dtype=np.float32)
+        self.b_pid = np.empty(self.m_data, dtype=np.int32)
+        self._L.hh_pa_get_rhs(self._h, self.b_data.ctypes.data_as(C.POINTER(C.c_float)),
+                              self.b_pid.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.hh_pa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            msg = self._L.hh_pa_last_error(self._h)
+            raise _lib.HeliconHipError(f"libhelicon_hip (Path A) error {rc}: {msg.decode() if msg else '?'}")
+
+    def matvec(self, x, d=None, root=None):
+        """[A diag(d); diag(root)] x — A = [A_data; A_hsym]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        d = None if d is None else np.ascontiguousarray(d, dtype=np.float64)
+        root = None if root is None else np.ascontiguousarray(root, dtype=np.float64)
+        y = np.empty(self.m + (self.n if root is not None else 0), dtype=np.float64)
+        self._check(self._L.hh_pa_matvec(self._h, _p(x), _p(d), _p(root), _p(y)))
+        return y
+
+    def rmatvec(self, y, d=None, root=None):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        d = None if d is None else np.ascontiguousarray(d, dtype=np.float64)
+        root = None if root is None else np.ascontiguousarray(root, dtype=np.float64)
+        g = np.empty(self.n, dtype=np.float64)
+        self._check(self._L.hh_pa_rmatvec(self._h, _p(y), _p(d), _p(root), _p(g)))
+        return g
+
+    def lsmr(self, rhs, d=None, root=None, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=1000):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        d = None if d is None else np.ascontiguousarray(d, dtype=np.float64)
+        root = None if root is None else np.ascontiguousarray(root, dtype=np.float64)
+        x = np.empty(self.n, dtype=np.float64)
+        info = (C.c_int * 2)()
+        norms = (C.c_double * 2)()
+        self._check(self._L.hh_pa_lsmr(self._h, _p(rhs), _p(d), _p(root), float(atol), float(btol), float(conlim),
+                                       int(maxiter), _p(x), info, norms))
+        return x, int(info[0]), int(info[1]), float(norms[0]), float(norms[1])
+
+
+# ---- scipy.optimize.lsq_linear(method="trf", lsq_solver="lsmr", lsmr_tol="auto") around the device operator ----------
+def _in_bounds(x, lb, ub):
+    return np.all((x >= lb) & (x <= ub))
+
+
+def _reflect(y, lb, ub):  # common.py: reflective_transformation (finite bounds on both sides, or none)
+    if _in_bounds(y, lb, ub):
+        return y
+    d = ub - lb
+    t = np.remainder(y - lb, 2 * d)
+    return lb + np.minimum(t, 2 * d - t)
+
+
+def _active(x, lb, ub, rtol=1e-10):
+    act = np.zeros_like(x, dtype=int)
+    if rtol == 0:
+        act[x <= lb] = -1
+        act[x >= ub] = 1
+        return act
+    lower, upper = x - lb, ub - x
+    lt, ut = rtol * np.maximum(1, np.abs(lb)), rtol * np.maximum(1, np.abs(ub))
+    act[lower <= np.minimum(upper, lt)] = -1
+    act[upper <= np.minimum(lower, ut)] = 1
+    return act
+
+
+def _strictly_feasible(x, lb, ub, rstep=1e-10):
+    xn = x.copy()
+    act = _active(x, lb, ub, rstep)
+    lo, up = act == -1, act == 1
+    if rstep == 0:
+        xn[lo] = np.nextafter(lb[lo], ub[lo])
+        xn[up] = np.nextafter(ub[up], lb[up])
+    else:
+        xn[lo] = lb[lo] + rstep * np.maximum(1, np.abs(lb[lo]))
+        xn[up] = ub[up] - rstep * np.maximum(1, np.abs(ub[up]))
+    tight = (xn < lb) | (xn > ub)
+    xn[tight] = 0.5 * (lb[tight] + ub[tight])
+    return xn
+
+
+def _step_to_bound(x, s, lb, ub):
+    nz = np.nonzero(s)
+    steps = np.full_like(x, np.inf)
+    with np.errstate(over="ignore"):
+        steps[nz] = np.maximum((lb - x)[nz] / s[nz], (ub - x)[nz] / s[nz])
+    mn = np.min(steps)
+    return mn, np.equal(steps, mn) * np.sign(s).astype(int)
+
+
+def _quad_1d(jdot, g, s, diag=None, s0=None):
+    v = jdot(s)
+    a = np.dot(v, v)
+    if diag is not None:
+        a += np.dot(s * diag, s)
+    a *= 0.5
+    b = np.dot(g, s)
+    if s0 is None:
+        return a, b
+    u = jdot(s0)
+    b += np.dot(u, v)
+    c = 0.5 * np.dot(u, u) + np.dot(g, s0)
+    if diag is not None:
+        b += np.dot(s0 * diag, s)
+        c += 0.5 * np.dot(s0 * diag, s0)
+    return a, b, c
+
+
+def _min_quad_1d(a, b, lb, ub, c=0):
+    t = [lb, ub]
+    if a != 0:
+        ext = -0.5 * b / a
+        if lb < ext < ub:
+            t.append(ext)
+    t = np.asarray(t)
+    y = t * (a * t + b) + c
+    k = np.argmin(y)
+    return t[k], y[k]
+
+
+def _eval_quad(jdot, g, s, diag=None):
+    js = jdot(s)
+    q = np.dot(js, js)
+    if diag is not None:
+        q += np.dot(s * diag, s)
+    return 0.5 * q + np.dot(s, g)
+
+
+def _solve_bounded(P: PathAProblem, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxiter=1000):
+    """lsq_linear(A, b, bounds=(lb, ub), tol, max_iter, lsmr_maxiter, lsmr_tol="auto"): unconstrained LSMR first; if it
+    leaves the box, the trust-region-reflective iteration (every LSMR solve and every product with A on the device)."""
+    n = P.n
+    x_lsq = P.lsmr(b, atol=1e-2 * tol, btol=1e-2 * tol, maxiter=lsmr_maxiter)[0]
+    if not np.isfinite(lb) and not np.isfinite(ub):
+        return x_lsq, 3, 0
+    lb = np.full(n, lb, dtype=np.float64)
+    ub = np.full(n, ub, dtype=np.float64)
+    if _in_bounds(x_lsq, lb, ub):
+        return x_lsq, 3, 0
+    x = _strictly_feasible(_reflect(x_lsq, lb, ub), lb, ub, rstep=0.1)
+    r = P.matvec(x) - b
+    g = P.rmatvec(r)
+    cost = 0.5 * np.dot(r, r)
+    status, it = None, -1
+    adot = P.matvec
+    for it in range(max_iter):
+        v, dv = np.ones(n), np.zeros(n)          # CL_scaling_vector
+        mk = g < 0
+        v[mk] = ub[mk] - x[mk]
+        dv[mk] = -1
+        mk = g > 0
+        v[mk] = x[mk] - lb[mk]
+        dv[mk] = 1
+        g_norm = np.linalg.norm(g * v, ord=np.inf)
+        if g_norm < tol:
+            status = 1
+            break
+        diag_h = g * dv
+        root = diag_h ** 0.5
+        d = v ** 0.5
+        g_h = d * g
+        ahdot = lambda s_, d=d: P.matvec(s_, d=d)  # noqa: E731
+        eta = 1e-2 * min(0.5, g_norm)
+        ltol = max(EPS, min(0.1, eta * g_norm))
+        p_h = -P.lsmr(np.concatenate((r, np.zeros(n))), d=d, root=root, atol=ltol, btol=ltol, maxiter=lsmr_maxiter)[0]
+        p = d * p_h
+        p_dot_g = np.dot(p, g)
+        if p_dot_g > 0:
+            status = -1
+        theta = 1 - min(0.005, g_norm)
+        if _in_bounds(x + p, lb, ub):            # select_step
+            step = p
+        else:
+            p_stride, hits = _step_to_bound(x, p, lb, ub)
+            r_h = np.copy(p_h)
+            r_h[hits.astype(bool)] *= -1
+            rr = d * r_h
+            p = p * p_stride
+            p_h = p_h * p_stride
+            r_su, _ = _step_to_bound(x + p, rr, lb, ub)
+            r_sl = (1 - theta) * r_su
+            r_su *= theta
+            if r_su > 0:
+                a_, b_, c_ = _quad_1d(ahdot, g_h, r_h, s0=p_h, diag=diag_h)
+                r_stride, r_value = _min_quad_1d(a_, b_, r_sl, r_su, c=c_)
+                r_h = p_h + r_h * r_stride
+                rr = d * r_h
+            else:
+                r_value = np.inf
+            p_h = p_h * theta
+            p = p * theta
+            p_value = _eval_quad(ahdot, g_h, p_h, diag=diag_h)
+            ag_h = -g_h
+            ag = d * ag_h
+            ag_su, _ = _step_to_bound(x, ag, lb, ub)
+            ag_su *= theta
+            a_, b_ = _quad_1d(ahdot, g_h, ag_h, diag=diag_h)
+            ag_stride, ag_value = _min_quad_1d(a_, b_, 0, ag_su)
+            ag = ag * ag_stride
+            if p_value < r_value and p_value < ag_value:
+                step = p
+            elif r_value < p_value and r_value < ag_value:
+                step = rr
+            else:
+                step = ag
+        cost_change = -_eval_quad(adot, g, step)
+        if cost_change < 0:                      # backtracking (scipy keeps the old x here)
+            alpha = 1.0
+            while True:
+                x_new = _reflect(x + alpha * p, lb, ub)
+                step = x_new - x
+                cost_change = -_eval_quad(adot, g, step)
+                if cost_change > -0.1 * alpha * p_dot_g:
+                    break
+                alpha *= 0.5
+            if np.any(_active(x_new, lb, ub) != 0):
+                x_new = _strictly_feasible(_reflect(x + theta * alpha * p, lb, ub), lb, ub, rstep=0)
+                step = x_new - x
+                cost_change = -_eval_quad(adot, g, step)
+        else:
+            x = _strictly_feasible(x + step, lb, ub, rstep=0)
+        r = P.matvec(x) - b
+        g = P.rmatvec(r)
+        if cost_change < tol * cost:
+            status = 2
+        cost = 0.5 * np.dot(r, r)
+        if status is not None:
+            break
+    return x, (0 if status is None else status), it + 1
+
+
+def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, csym=1, tilt_degree=0, psi_degree=0,
+                    dy_pixel=0, thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
+                    reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
+                    reconstruct_length_3d_pixel=-1, sym_oversample=1, interpolation="nn", fsc_test=0,
+                    score_metric="cosine", target_apix2d=5.0, verbose=0, algorithm=dict(model="lsq"),
+                    refine_tilt_psi_dy_range=None, cpu=1, *, device=0):
+    """solver_linear_regression.py:31-547 for ``interpolation="nn"``, ``algorithm["model"] == "lsq"``, ``fsc_test=0``,
+    cosine score: returns ``((rec3d float32 (L3d, D3d, D3d), None, None), score)``."""
+    if interpolation != "nn":
+        raise NotImplementedError("the GPU slice of Path A provides nearest-neighbour interpolation")
+    if (algorithm or {}).get("model", "lsq") != "lsq":
+        raise NotImplementedError("the GPU slice of Path A provides model='lsq' (the scikit-learn models are not deterministic)")
+    if fsc_test:
+        raise NotImplementedError("half-set solves (fsc_test) are outside this slice")
+    if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
+        raise NotImplementedError("scores other than cosine need scikit-image")
+    if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):
+        raise NotImplementedError("tilt / psi / dy refinement is outside this slice")
+    img = np.asarray(projection_image)
+    d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
+    d2 = int(reconstruct_diameter_2d_pixel) if reconstruct_diameter_2d_pixel > 0 else img.shape[0]
+    l2 = int(reconstruct_length_2d_pixel) if reconstruct_length_2d_pixel > 0 else img.shape[1]
+    rmin = reconstruct_diameter_3d_inner_pixel / 2
+    rmax = d3 // 2 - 1
+    mask = get_cylindrical_mask(l3, d3, d3, rmin=rmin, rmax=rmax)
+    n3 = int(np.count_nonzero(mask))
+    target = min(2**26, int(max(d2 * l2, n3) * sym_oversample))                   # solver:148-150, 168-170
+    with PathAProblem(img, scale2d_to_3d=scale2d_to_3d, twist_degree=twist_degree, rise_pixel=rise_pixel, csym=csym,
+                      tilt_degree=tilt_degree, psi_degree=psi_degree, dy_pixel=dy_pixel,
+                      reconstruct_diameter_2d_pixel=d2, reconstruct_length_2d_pixel=l2, reconstruct_diameter_3d_pixel=d3,
+                      reconstruct_diameter_3d_inner_pixel=reconstruct_diameter_3d_inner_pixel,
+                      reconstruct_length_3d_pixel=l3, min_projection_lines=target, min_sym_pairs=target,
+                      device=device) as P:
+        if P.n != n3:
+            raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
+                             "the 3-D diameter): the reference's two masks would rank the voxels differently")
+        b = np.concatenate((P.b_data.astype(np.float64), np.zeros(P.m_sym)))
+        pitch_pixel = round(rise_pixel * 360 / abs(twist_degree))
+        positive = positive_constraint > 0 or (positive_constraint < 0 and pitch_pixel > round(l3 * 2))   # solver:352-355
+        lb, ub = (0.0, float(np.max(P.b_data))) if positive else (-np.inf, np.inf)                        # solver:245-256
+        x, _, _ = _solve_bounded(P, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxiter=1000)
+        x = x.astype(np.float32)
+        pred = P.matvec(x.astype(np.float64))[: P.m_data]
+        if thresh_fraction >= 0:
+            pred = np.clip(pred, 0, None)
+        score = cosine_similarity(pred, P.b_data.astype(np.float64))
+    rec3d = np.zeros(mask.shape, dtype=np.float32)
+    rec3d[mask] = x
+    return (rec3d, None, None), score

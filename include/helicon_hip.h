@@ -224,6 +224,41 @@ int hh_calibrate_traffic(hh_ctx* ctx, int mode, int64_t bytes);
 /* Algorithmic HBM bytes per candidate, B_alg(N) = 4 N^2 + 16 N (N/2 + 1). */
 int64_t hh_algorithmic_bytes(int n);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Path A, first slice: the reference's shipped scorer (sparse least squares + cosine) with a matrix-free
+ * nearest-neighbour projector.  Replaces, for interpolation="nn": build_A_data_matrix
+ * (webApps/denovo3D/solver_linear_regression.py:1304-1654), build_A_helical_sym_matrix (:847-1298) and the
+ * scipy.sparse.linalg.lsmr calls behind scipy.optimize.lsq_linear (:258-269).  The bounded trust-region iteration,
+ * the positivity rule and the score stay on the host: helicon_amd/solver.py (lsq_reconstruct, :31-547).
+ * An hh_pa is one candidate's implicit system: rows = [projection rays with at least one sample in the cylinder,
+ * in the reference's (symmetry operation, k, j) order] + [symmetry constraints x_i - x_j = 0]; unknowns = voxels of
+ * the cylinder in C-order rank.  Vectors cross this boundary as host float64 arrays. */
+typedef struct hh_pa hh_pa;
+typedef struct hh_pa_params {
+  double scale2d_to_3d, twist_degree, rise_pixel;
+  int32_t csym;
+  double tilt_degree, psi_degree, dy_pixel;
+  int32_t reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, reconstruct_diameter_3d_pixel,
+      reconstruct_diameter_3d_inner_pixel, reconstruct_length_3d_pixel;
+  int64_t min_projection_lines;   /* stop adding symmetry operations once the data rows exceed this (solver:1647) */
+  int64_t min_sym_pairs;          /* symmetry rows wanted (solver:1275); 0 = no symmetry block */
+} hh_pa_params;
+int hh_pa_create(hh_pa** out, int device, const float* image, int ny, int nx, const hh_pa_params* params);
+void hh_pa_destroy(hh_pa* pa);
+const char* hh_pa_last_error(const hh_pa* pa);
+/* dims = {unknowns, data rows, symmetry rows, symmetry operations used} */
+int hh_pa_dims(const hh_pa* pa, int64_t dims[4]);
+/* b (pixel value of every data row) and b_pid (k * D2d + j), solver:1548-1549 */
+int hh_pa_get_rhs(const hh_pa* pa, float* b, int32_t* b_pid);
+/* y = Op x and g = Op^T y for Op = [A diag(d); diag(root)] (d, root may be NULL: Op = A = [A_data; A_hsym]);
+ * y has data rows + symmetry rows (+ unknowns when root is given) entries. */
+int hh_pa_matvec(hh_pa* pa, const double* x, const double* d, const double* root, double* y);
+int hh_pa_rmatvec(hh_pa* pa, const double* y, const double* d, const double* root, double* g);
+/* scipy.sparse.linalg.lsmr(Op, rhs, atol, btol, conlim, maxiter) with all vectors on the device;
+ * info = {istop, itn}, norms = {normr, normar} (either may be NULL). */
+int hh_pa_lsmr(hh_pa* pa, const double* rhs, const double* d, const double* root, double atol, double btol, double conlim,
+               int maxiter, double* x_out, int info[2], double norms[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,6 +175,93 @@ def g3b_general_sizes():
     np.savez_compressed(OUT / "g3b_general_sizes.npz", **arrs)
 
 
+def g4_path_a():
+    """Path A building blocks: mask counts, symmetry-pair lists, Halton index lists,
+    back-projected coordinates, and the CSR triplets of the NN data matrix and of the NN symmetry matrix on the inputs of
+    the reference's own structural tests (tests/test_denovo3D_solver.py:8-175)."""
+    from scipy.stats import qmc
+
+    from helicon.webApps.denovo3D import solver_linear_regression as S
+
+    arrs = {}
+    for k, (nz, ny, nx, rmin, rmax) in enumerate([(4, 36, 36, 0, 17), (4, 64, 64, 0, 17), (8, 8, 8, 0, 3), (6, 20, 20, 3, 9)]):
+        m = analysis.get_cylindrical_mask(nz, ny, nx, rmin=rmin, rmax=rmax)
+        arrs[f"mask{k}_args"] = np.asarray([nz, ny, nx, rmin, rmax])
+        arrs[f"mask{k}_count"] = np.asarray([np.count_nonzero(m)])
+        arrs[f"mask{k}_first_nonzero"] = np.argwhere(m)[:5]
+    for n in (7, 9, 16, 73):
+        arrs[f"halton_{n}"] = qmc.Halton(d=1, scramble=False).integers(l_bounds=0, u_bounds=n, n=n)[:, 0]
+    for k, (tw, rs, cs, nz) in enumerate([(30, 5, 1, 20), (30, 5, 2, 20), (-41.5, 3.7, 3, 12)]):
+        pairs = S.sorted_hsym_csym_pairs(tw, rs, cs, nz)
+        arrs[f"pairs{k}_args"] = np.asarray([tw, rs, cs, nz], dtype=np.float64)
+        arrs[f"pairs{k}"] = np.asarray([[p[0], p[1], p[2], p[3], p[4], *p[5][0], *p[5][1]] for p in pairs], dtype=np.float64)
+    img4 = np.arange(16, dtype=np.float32).reshape(4, 4)
+    (X, Y, Z), vals = S.back_project_2d_coords_to_3d_coords(img4, 1.0, 4, 4)
+    arrs.update(bp_image=img4, bp_X=X, bp_Y=Y, bp_Z=Z, bp_vals=vals)
+    (X, Y, Z), vals = S.back_project_2d_coords_to_3d_coords(np.arange(48, dtype=np.float32).reshape(6, 8), 1.5, 4, 6)
+    arrs.update(bp2_X=X, bp2_Y=Y, bp2_Z=Z, bp2_vals=vals)
+    cases = [
+        # image, scale, twist, rise, csym, tilt, psi, dy, D2d, L2d, D3d, D3d_inner, L3d, min_lines
+        (np.eye(8, dtype=np.float32), 1.0, 30.0, 2.0, 1, 0.0, 0.0, 0.0, 8, 8, 8, 0, 8, 64),
+        (np.random.default_rng(4).random((12, 16)).astype(np.float32), 1.0, -41.5, 3.7, 2, 3.0, -2.0, 0.5, 10, 14, 10, 2, 6, 300),
+    ]
+    for k, c in enumerate(cases):
+        A, b, pid = S.build_A_data_matrix.func(*c, "nn", 0, 1) if hasattr(S.build_A_data_matrix, "func") else \
+            S.build_A_data_matrix(*c, "nn", verbose=0, cpu=1)
+        A = A.tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        arrs[f"adata{k}_image"] = c[0]
+        arrs[f"adata{k}_args"] = np.asarray(c[1:], dtype=np.float64)
+        arrs[f"adata{k}_indptr"], arrs[f"adata{k}_indices"], arrs[f"adata{k}_data"] = A.indptr, A.indices, A.data
+        arrs[f"adata{k}_shape"] = np.asarray(A.shape)
+        arrs[f"adata{k}_b"], arrs[f"adata{k}_pid"] = b, pid
+    for k, c in enumerate([(8, 8, 8, 30.0, 2.0, 1, 0.0, 3.0, 50), (6, 12, 12, -41.5, 3.7, 2, 1.0, 5.0, 400)]):
+        fn = getattr(S.build_A_helical_sym_matrix, "func", S.build_A_helical_sym_matrix)
+        A, b = fn(*c, "nn", 0)
+        A = A.tocsr()
+        A.sort_indices()
+        arrs[f"ahsym{k}_args"] = np.asarray(c, dtype=np.float64)
+        arrs[f"ahsym{k}_indptr"], arrs[f"ahsym{k}_indices"], arrs[f"ahsym{k}_data"] = A.indptr, A.indices, A.data
+        arrs[f"ahsym{k}_shape"] = np.asarray(A.shape)
+    np.savez_compressed(OUT / "g4_path_a.npz", **arrs)
+
+
+def g5_lsq():
+    """lsq_reconstruct (model lsq, interpolation nn, cpu 1: the deterministic configuration) on the reference test's
+    seed-42 rand(12, 12) (tests/test_denovo3D_solver.py:179-199) and on a 32 x 32 synthetic helix at three twists."""
+    from helicon.webApps.denovo3D import solver_linear_regression as S
+
+    arrs = {}
+    np.random.seed(42)
+    img = np.random.rand(12, 12).astype(np.float32)
+    kw = dict(scale2d_to_3d=1.0, twist_degree=30.0, rise_pixel=2.0, csym=1, reconstruct_diameter_2d_pixel=8,
+              reconstruct_diameter_3d_pixel=8, reconstruct_length_2d_pixel=8, reconstruct_length_3d_pixel=8,
+              sym_oversample=1, interpolation="nn", algorithm=dict(model="lsq"), cpu=1)
+    (rec, _, _), score = S.lsq_reconstruct(projection_image=img, **kw)
+    arrs.update(seed42_image=img, seed42_rec3d=rec, seed42_score=np.asarray([score]),
+                seed42_args=np.asarray([1.0, 30.0, 2.0, 1, 8, 8, 8, 8, 1], dtype=np.float64))
+    n, apix = 32, 5.0
+    d, br = 0.4 * n * apix, 2 * apix
+    clean = utils.simulate_helical_projection(1, 29.0, 10.0, 1, d, br, 0, 0, n, n, apix)
+    himg = (clean / clean.max()).astype(np.float32)
+    arrs["helix_image"] = himg
+    tws = np.asarray([25.0, 29.0, 33.0])
+    scores = []
+    for tw in tws:
+        (rec, _, _), sc = S.lsq_reconstruct(projection_image=himg, scale2d_to_3d=1.0, twist_degree=float(tw), rise_pixel=2.0,
+                                            csym=1, reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20,
+                                            reconstruct_length_2d_pixel=32, reconstruct_length_3d_pixel=6, sym_oversample=1,
+                                            interpolation="nn", algorithm=dict(model="lsq"), cpu=1)
+        scores.append(sc)
+        if tw == 29.0:
+            arrs["helix_rec3d_29"] = rec
+    arrs["helix_twists"] = tws
+    arrs["helix_scores"] = np.asarray(scores)
+    arrs["helix_args"] = np.asarray([1.0, 2.0, 1, 20, 20, 32, 6, 1], dtype=np.float64)
+    np.savez_compressed(OUT / "g5_lsq.npz", **arrs)
+
+
 def g6_filters():
     rng = np.random.default_rng(6)
     x = rng.normal(size=(32, 32))
@@ -234,6 +321,8 @@ if __name__ == "__main__":
     g2_scores()
     g3_composed()
     g3b_general_sizes()
+    g4_path_a()
+    g5_lsq()
     g6_filters()
     g7_helical_sym()
     (OUT / "VERSIONS.json").write_text(json.dumps(versions(), indent=1) + "\n")

@@ -1,0 +1,106 @@
+"""Path A on the GPU (helicon_amd.solver, hh_pa_* of the C ABI) against the oracle's sparse matrices and against
+outputs of the reference itself (fixtures G4, G5): the implicit projector equals the reference's CSR matrices, LSMR on
+the device equals scipy's, and lsq_reconstruct reproduces the reference's cosine scores (1e-4) and volumes.
+solver_linear_regression.py:31-547, 847-1298, 1304-1654."""
+import numpy as np
+import pytest
+from scipy.sparse import vstack
+
+from helicon_amd.solver import PathAProblem, lsq_reconstruct
+from oracle import path_a as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem_and_oracle(image, args, min_sym):
+    s2, tw, rs, cs, tilt, psi, dy, d2, l2, d3, d3i, l3, min_lines = args
+    cs, d2, l2, d3, d3i, l3, min_lines = (int(v) for v in (cs, d2, l2, d3, d3i, l3, min_lines))
+    P = PathAProblem(image, scale2d_to_3d=s2, twist_degree=tw, rise_pixel=rs, csym=cs, tilt_degree=tilt, psi_degree=psi,
+                     dy_pixel=dy, reconstruct_diameter_2d_pixel=d2, reconstruct_length_2d_pixel=l2,
+                     reconstruct_diameter_3d_pixel=d3, reconstruct_diameter_3d_inner_pixel=d3i,
+                     reconstruct_length_3d_pixel=l3, min_projection_lines=min_lines, min_sym_pairs=min_sym)
+    Ad, b, pid = A.build_A_data_matrix(image, s2, tw, rs, cs, tilt, psi, dy, d2, l2, d3, d3i, l3, min_lines)
+    As, _ = A.build_A_helical_sym_matrix(l3, d3, d3, tw, rs, cs, d3i / 2, d3 // 2 - 1, min_sym) if min_sym else (None, None)
+    return P, Ad, b, pid, As
+
+
+def test_projector_equals_the_reference_matrices(golden_dir):
+    g = np.load(golden_dir / "g4_path_a.npz")
+    rng = np.random.default_rng(0)
+    for k, min_sym in ((0, 64), (1, 300)):
+        image, args = g[f"adata{k}_image"], g[f"adata{k}_args"]
+        P, Ad, b, pid, As = _problem_and_oracle(image, args, min_sym)
+        with P:
+            assert (P.n, P.m_data) == (Ad.shape[1], Ad.shape[0]) and P.m_sym == (As.shape[0] if As is not None else 0)
+            np.testing.assert_array_equal(P.b_data, g[f"adata{k}_b"])      # the reference's own b and pixel ids
+            np.testing.assert_array_equal(P.b_pid, g[f"adata{k}_pid"])
+            full = vstack((Ad, As)).tocsr() if As is not None else Ad
+            # column by column: the implicit matrix IS the reference's matrix (hit counts and +-1 pairs)
+            dense = np.stack([P.matvec(np.eye(P.n)[c]) for c in range(P.n)], axis=1)
+            np.testing.assert_array_equal(dense, full.toarray().astype(np.float64))
+            x = rng.normal(size=P.n)
+            y = rng.normal(size=P.m)
+            np.testing.assert_allclose(P.matvec(x), full @ x, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(P.rmatvec(y), full.T @ y, rtol=0, atol=1e-10)
+            # the trust-region step's augmented operator [A diag(d); diag(root)]
+            d, root = rng.uniform(0.1, 2.0, P.n), rng.uniform(0.0, 1.0, P.n)
+            np.testing.assert_allclose(P.matvec(x, d=d, root=root), np.r_[full @ (x * d), root * x], rtol=0, atol=1e-10)
+            ya = rng.normal(size=P.m + P.n)
+            np.testing.assert_allclose(P.rmatvec(ya, d=d, root=root), d * (full.T @ ya[: P.m]) + root * ya[P.m:], rtol=0, atol=1e-10)
+
+
+def test_device_lsmr_equals_scipy():
+    from scipy.sparse.linalg import lsmr as sp_lsmr
+
+    rng = np.random.default_rng(5)
+    image = rng.random((24, 28)).astype(np.float32)
+    args = (1.0, 27.0, 2.3, 2, 0.0, 0.0, 0.0, 16, 24, 16, 0, 6, 2000)
+    P, Ad, b, pid, As = _problem_and_oracle(image, args, 1500)
+    with P:
+        full = vstack((Ad, As)).tocsr()
+        rhs = np.r_[b.astype(np.float64), np.zeros(As.shape[0])]
+        x, istop, itn, normr, normar = P.lsmr(rhs, atol=1e-8, btol=1e-8, maxiter=2000)
+        ref = sp_lsmr(full.astype(np.float64), rhs, atol=1e-8, btol=1e-8, maxiter=2000)
+        assert istop == ref[1] and abs(itn - ref[2]) <= 2
+        np.testing.assert_allclose(x, ref[0], rtol=0, atol=1e-5 * np.abs(ref[0]).max())
+        assert normr == pytest.approx(ref[3], rel=1e-6)
+        for it in (1, 4, 12):   # the recurrences, before rounding noise separates two implementations
+            xa = P.lsmr(rhs, atol=0, btol=0, conlim=0, maxiter=it)[0]
+            xb = sp_lsmr(full.astype(np.float64), rhs, atol=0, btol=0, conlim=0, maxiter=it)[0]
+            np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-11 * max(1.0, np.abs(xb).max()))
+
+
+def test_lsq_reconstruct_reproduces_the_reference(golden_dir):
+    """Fixture G5: the reference test's seed-42 image (tests/test_denovo3D_solver.py:179-199; the positivity rule makes
+    it a bounded solve) and a 32 x 32 helix at three twists — cosine scores within 1e-4, volumes within the solver's
+    own tolerance, arg-max over the twists at the truth."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    s2, tw, rs, cs, d2, d3, l2, l3, ov = g["seed42_args"]
+    (rec, h1, h2), score = lsq_reconstruct(g["seed42_image"], s2, tw, rs, int(cs), reconstruct_diameter_2d_pixel=int(d2),
+                                           reconstruct_diameter_3d_pixel=int(d3), reconstruct_length_2d_pixel=int(l2),
+                                           reconstruct_length_3d_pixel=int(l3), sym_oversample=ov, interpolation="nn")
+    assert h1 is None and h2 is None and rec.shape == (8, 8, 8) and rec.dtype == np.float32
+    assert score == pytest.approx(float(g["seed42_score"][0]), abs=1e-4)
+    assert np.abs(rec - g["seed42_rec3d"]).max() < 5e-3 * np.abs(g["seed42_rec3d"]).max()
+    s2, rs, cs, d2, d3, l2, l3, ov = g["helix_args"]
+    scores = []
+    for tw, want in zip(g["helix_twists"], g["helix_scores"]):
+        (rec, _, _), score = lsq_reconstruct(g["helix_image"], s2, float(tw), rs, int(cs), reconstruct_diameter_2d_pixel=int(d2),
+                                             reconstruct_diameter_3d_pixel=int(d3), reconstruct_length_2d_pixel=int(l2),
+                                             reconstruct_length_3d_pixel=int(l3), sym_oversample=ov)
+        assert score == pytest.approx(float(want), abs=1e-4), tw
+        scores.append(score)
+        if tw == 29.0:
+            assert np.abs(rec - g["helix_rec3d_29"]).max() < 5e-3 * np.abs(g["helix_rec3d_29"]).max()
+    assert int(np.argmax(scores)) == 1
+    # unbounded branch and the oracle, on a case the positivity rule leaves free
+    (rec_u, _, _), s_u = lsq_reconstruct(g["helix_image"], 1.0, 29.0, 2.0, 1, positive_constraint=0, reconstruct_diameter_2d_pixel=20,
+                                         reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=32,
+                                         reconstruct_length_3d_pixel=6)
+    (rec_o, _, _), s_o = A.lsq_reconstruct(g["helix_image"], 1.0, 29.0, 2.0, 1, positive_constraint=0,
+                                           reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20,
+                                           reconstruct_length_2d_pixel=32, reconstruct_length_3d_pixel=6)
+    assert s_u == pytest.approx(s_o, abs=1e-5)
+    with pytest.raises(NotImplementedError):
+        lsq_reconstruct(g["helix_image"], 1.0, 29.0, 2.0, interpolation="linear", reconstruct_diameter_3d_pixel=20,
+                        reconstruct_length_3d_pixel=6)

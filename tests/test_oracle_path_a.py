@@ -1,0 +1,100 @@
+"""The Path-A oracle (oracle/path_a.py) against outputs of the reference itself (fixtures G4, G5 of
+tests/golden/make_golden.py): index structures bit for bit, least-squares scores to the solver's own tolerance."""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+from oracle import path_a as A
+
+
+def _csr(g, tag):
+    return csr_matrix((g[f"{tag}_data"], g[f"{tag}_indices"], g[f"{tag}_indptr"]), shape=tuple(g[f"{tag}_shape"]))
+
+
+def test_g4_masks_halton_pairs_and_back_projection(golden_dir):
+    g = np.load(golden_dir / "g4_path_a.npz")
+    for k in range(4):
+        nz, ny, nx, rmin, rmax = g[f"mask{k}_args"]
+        m = A.get_cylindrical_mask(int(nz), int(ny), int(nx), rmin=rmin, rmax=rmax)
+        assert np.count_nonzero(m) == int(g[f"mask{k}_count"][0])
+        np.testing.assert_array_equal(np.argwhere(m)[:5], g[f"mask{k}_first_nonzero"])
+    assert not A.get_cylindrical_mask(3, 3, 3)[0, 1, 1] and A.get_cylindrical_mask(5, 5, 5)[2, 2, 2]  # test_analysis.py:40-45
+    for n in (7, 9, 16, 73):
+        np.testing.assert_array_equal(A.halton_order(n), g[f"halton_{n}"])
+    assert len(set(A.halton_order(73).tolist())) == 65                       # repeats and omissions are kept
+    for k in range(3):
+        tw, rs, cs, nz = g[f"pairs{k}_args"]
+        got = A.sorted_hsym_csym_pairs(tw, rs, int(cs), int(nz))
+        flat = np.asarray([[p[0], p[1], p[2], p[3], p[4], *p[5][0], *p[5][1]] for p in got], dtype=np.float64)
+        np.testing.assert_array_equal(flat, g[f"pairs{k}"])
+    (X, Y, Z), vals = A.back_project_2d_coords_to_3d_coords(g["bp_image"], 1.0, 4, 4)
+    for got, want in ((X, g["bp_X"]), (Y, g["bp_Y"]), (Z, g["bp_Z"]), (vals, g["bp_vals"])):
+        np.testing.assert_array_equal(got, want)
+    (X, Y, Z), vals = A.back_project_2d_coords_to_3d_coords(np.arange(48, dtype=np.float32).reshape(6, 8), 1.5, 4, 6)
+    for got, want in ((X, g["bp2_X"]), (Y, g["bp2_Y"]), (Z, g["bp2_Z"]), (vals, g["bp2_vals"])):
+        np.testing.assert_array_equal(got, want)
+
+
+def test_g4_data_and_symmetry_matrices_are_bit_exact(golden_dir):
+    g = np.load(golden_dir / "g4_path_a.npz")
+    for k in range(2):
+        a = g[f"adata{k}_args"]
+        Am, b, pid = A.build_A_data_matrix(g[f"adata{k}_image"], a[0], a[1], a[2], int(a[3]), a[4], a[5], a[6], int(a[7]),
+                                           int(a[8]), int(a[9]), int(a[10]), int(a[11]), int(a[12]))
+        Am.sum_duplicates()
+        Am.sort_indices()
+        ref = _csr(g, f"adata{k}")
+        assert Am.shape == ref.shape
+        np.testing.assert_array_equal(Am.indptr, ref.indptr)
+        np.testing.assert_array_equal(Am.indices, ref.indices)
+        np.testing.assert_array_equal(Am.data, ref.data)
+        np.testing.assert_array_equal(b, g[f"adata{k}_b"])
+        np.testing.assert_array_equal(pid, g[f"adata{k}_pid"])
+    for k in range(2):
+        a = g[f"ahsym{k}_args"]
+        Am, b = A.build_A_helical_sym_matrix(int(a[0]), int(a[1]), int(a[2]), a[3], a[4], int(a[5]), a[6], a[7], int(a[8]))
+        Am.sort_indices()
+        ref = _csr(g, f"ahsym{k}")
+        assert Am.shape == ref.shape and len(b) == ref.shape[0] and not b.any()
+        np.testing.assert_array_equal(Am.indptr, ref.indptr)
+        np.testing.assert_array_equal(Am.indices, ref.indices)
+        np.testing.assert_array_equal(Am.data, ref.data)
+
+
+def test_lsmr_restatement_against_scipy():
+    from scipy.sparse import random as sprandom
+    from scipy.sparse.linalg import lsmr as sp_lsmr
+
+    rng = np.random.default_rng(0)
+    M = sprandom(300, 120, density=0.05, random_state=1, format="csr")
+    b = rng.normal(size=300)
+    x, istop, itn, normr, normar = A.lsmr(M, b, atol=1e-8, btol=1e-8, maxiter=500)
+    ref = sp_lsmr(M, b, atol=1e-8, btol=1e-8, maxiter=500)
+    assert (istop, itn) == (ref[1], ref[2])
+    np.testing.assert_allclose(x, ref[0], rtol=0, atol=1e-6)     # near convergence the iterates carry rounding noise
+    assert normr == pytest.approx(ref[3], rel=1e-10)
+    for it in (1, 3, 10):                                         # the recurrences themselves, before the noise grows
+        xa = A.lsmr(M, b, atol=0, btol=0, conlim=0, maxiter=it)[0]
+        xb = sp_lsmr(M, b, atol=0, btol=0, conlim=0, maxiter=it)[0]
+        np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-12)
+
+
+def test_g5_lsq_reconstruct_scores_and_volumes(golden_dir):
+    """The reference runs scipy's LSMR on float32 operands (tolerance 1e-4); the oracle iterates in float64: scores
+    agree to 1e-4, the volume to the solver's tolerance."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    s2, tw, rs, cs, d2, d3, l2, l3, ov = g["seed42_args"]
+    (rec, h1, h2), score = A.lsq_reconstruct(g["seed42_image"], s2, tw, rs, int(cs), reconstruct_diameter_2d_pixel=int(d2),
+                                             reconstruct_diameter_3d_pixel=int(d3), reconstruct_length_2d_pixel=int(l2),
+                                             reconstruct_length_3d_pixel=int(l3), sym_oversample=ov)
+    assert h1 is None and h2 is None and rec.shape == (8, 8, 8) and rec.dtype == np.float32
+    assert score == pytest.approx(float(g["seed42_score"][0]), abs=1e-4)
+    assert np.abs(rec - g["seed42_rec3d"]).max() < 5e-3 * np.abs(g["seed42_rec3d"]).max()
+    s2, rs, cs, d2, d3, l2, l3, ov = g["helix_args"]
+    for tw, want in zip(g["helix_twists"], g["helix_scores"]):
+        (rec, _, _), score = A.lsq_reconstruct(g["helix_image"], s2, float(tw), rs, int(cs), reconstruct_diameter_2d_pixel=int(d2),
+                                               reconstruct_diameter_3d_pixel=int(d3), reconstruct_length_2d_pixel=int(l2),
+                                               reconstruct_length_3d_pixel=int(l3), sym_oversample=ov)
+        assert score == pytest.approx(float(want), abs=1e-4), tw
+        if tw == 29.0:
+            assert np.abs(rec - g["helix_rec3d_29"]).max() < 5e-3 * np.abs(g["helix_rec3d_29"]).max()
