@@ -37,12 +37,13 @@ def pick(d, frag):
     raise KeyError(frag)
 
 
-def main(fetch_dir, write_dir, n=512, batch=256, out=None):
+def main(fetch_dir, write_dir, source=None, n=512, batch=256, out=None):
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
     f_unit = CALIB_BYTES / pick(fetch, "k_calib_read")[0]    # bytes per FETCH_SIZE unit, K_B's read shape
     w_unit = CALIB_BYTES / pick(write, "k_calib_write")[0]   # bytes per WRITE_SIZE unit, K_A's write shape
-    res = {"calibration": {"bytes": CALIB_BYTES, "bytes_per_FETCH_SIZE_unit": f_unit,
+    res = {"source": source or "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/traffic_run.py",
+           "calibration": {"bytes": CALIB_BYTES, "bytes_per_FETCH_SIZE_unit": f_unit,
                            "bytes_per_WRITE_SIZE_unit": w_unit,
                            "calib_read_FETCH_SIZE": pick(fetch, "k_calib_read")[0],
                            "calib_write_WRITE_SIZE": pick(write, "k_calib_write")[0],
@@ -74,4 +75,4 @@ def main(fetch_dir, write_dir, n=512, batch=256, out=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])

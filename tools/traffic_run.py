@@ -26,7 +26,8 @@ eng.set_geometry(apix=apix, helical_diameter=0.4 * n * apix, ball_radius=2 * api
 clean = eng.simulate(1.2, 4.75, 1)
 img = (clean + np.random.default_rng(0).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
 eng.set_reference(img)
-grid = H.build_grid(H.sweep_axis(0.01, 4.00, 0.01), H.sweep_axis(4.000, 5.245, 0.005), (1,), tube_length=n * apix)
+nt = 400 if n <= 512 else 100  # (the 1024 side is four times the work per candidate)
+grid = H.build_grid(H.sweep_axis(0.01, 4.00, 0.01)[:nt], H.sweep_axis(4.000, 5.245, 0.005), (1,), tube_length=n * apix)
 for mode in (2, 1, 0):  # fused; run tables + second pass; raster + two transforms per candidate
     eng.set_table_path(mode)
     scores = eng.sweep(grid.params)
