@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress must fail, not hang the box: 300 s per test when pytest-timeout is
+    installed (it is on the image)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(300))
