@@ -97,6 +97,9 @@
 #ifndef HH_KF_PRIO
 #define HH_KF_PRIO 0       // fused pass: s_setprio level of the late wavefronts (0 = off)
 #endif
+#ifndef HH_POISON
+#define HH_POISON 0        // test builds: NaN in every factor row the fused pass has no business reading
+#endif
 #ifndef HH_XCD_MAP
 #define HH_XCD_MAP 1       // fused pass: all ky blocks of a layer of candidates on one XCD (shared L2)
 #endif
@@ -1465,6 +1468,10 @@ __device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b, fl
   if ((x & 3) == 0) cgo[x >> 2] = cg;
   __syncthreads();
   if (x < 4) cgo[N / 4 + x] = *kc_s;
+#if HH_POISON
+  // sanitizer build: factor rows past the candidate's row count must never be read by the fused pass
+  for (int k = *kc_s; k < a.kg; ++k) a.eg[((size_t)b * a.kg + k) * N + x] = __builtin_nanf("");
+#endif
 }
 
 template <int N>
