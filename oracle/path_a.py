@@ -144,7 +144,7 @@ def build_A_data_matrix(image, scale2d_to_3d, twist_degree, rise_pixel, csym, ti
                         reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, reconstruct_diameter_3d_pixel,
                         reconstruct_diameter_3d_inner_pixel, reconstruct_length_3d_pixel, min_projection_lines,
                         interpolation="nn"):
-    assert interpolation == "nn", "the oracle restates the nearest-neighbour branch"
+    assert interpolation in ("nn", "linear"), "the oracle restates the nearest-neighbour and the trilinear branch"
     (X0, Y0, Z0), pixel_vals = back_project_2d_coords_to_3d_coords(image, scale2d_to_3d, reconstruct_diameter_2d_pixel,
                                                                    reconstruct_length_2d_pixel)
     rmin = reconstruct_diameter_3d_inner_pixel / 2
@@ -168,20 +168,45 @@ def build_A_data_matrix(image, scale2d_to_3d, twist_degree, rise_pixel, csym, ti
         X = coords[:, 0].reshape((nz, ny, nx)) + nx // 2
         Y = coords[:, 1].reshape((nz, ny, nx)) + ny // 2
         Z = coords[:, 2].reshape((nz, ny, nx)) + reconstruct_length_3d_pixel // 2
-        zi, yi, xi = np.rint(Z).astype(np.int64), np.rint(Y).astype(np.int64), np.rint(X).astype(np.int64)
-        ok = (zi >= 0) & (zi <= mz - 1) & (yi >= 0) & (yi <= my - 1) & (xi >= 0) & (xi <= mx - 1)
-        idx = np.full(zi.shape, -1, dtype=np.int64)
-        idx[ok] = rank[zi[ok], yi[ok], xi[ok]]   # -1 outside the cylinder
-        hit = idx >= 0                             # [k, j, i]
-        has = hit.any(axis=2)                      # rows exist for rays with at least one sample in the mask
-        row_of = np.cumsum(has.ravel()).reshape(has.shape) - 1
-        kk, jj, _ = np.nonzero(hit)
-        rows = row_of[kk, jj]
-        cols = idx[hit]
-        n_rows = int(has.sum())
+        if interpolation == "linear":
+            # solver:1414-1503: int() truncates towards zero; a sample counts when its whole 2x2x2 cell lies in the
+            # cylinder; weights in float64, summed per (row, voxel), stored as float32
+            zi, yi, xi = np.trunc(Z).astype(np.int64), np.trunc(Y).astype(np.int64), np.trunc(X).astype(np.int64)
+            ok = (zi >= 0) & (zi + 1 <= mz - 1) & (yi >= 0) & (yi + 1 <= my - 1) & (xi >= 0) & (xi + 1 <= mx - 1)
+            corner = np.full((8,) + zi.shape, -1, dtype=np.int64)
+            for c, (dz, dy_, dx) in enumerate(itertools.product((0, 1), (0, 1), (0, 1))):   # 000, 001, 010, ... (z, y, x)
+                corner[c][ok] = rank[zi[ok] + dz, yi[ok] + dy_, xi[ok] + dx]
+            hit = ok & (corner >= 0).all(axis=0)
+            zf, yf, xf = Z - zi, Y - yi, X - xi
+            wts = [(1 - zf) * (1 - yf) * (1 - xf), (1 - zf) * (1 - yf) * xf, (1 - zf) * yf * (1 - xf), (1 - zf) * yf * xf,
+                   zf * (1 - yf) * (1 - xf), zf * (1 - yf) * xf, zf * yf * (1 - xf), zf * yf * xf]
+            has = hit.any(axis=2)
+            row_of = np.cumsum(has.ravel()).reshape(has.shape) - 1
+            kk, jj, _ = np.nonzero(hit)
+            rows = np.tile(row_of[kk, jj], 8)
+            cols = np.concatenate([corner[c][hit] for c in range(8)])
+            vals = np.concatenate([wts[c][hit] for c in range(8)])
+            n_rows = int(has.sum())
+            if n_rows:
+                m64 = csr_matrix((vals, (rows, cols)), shape=(n_rows, n_x), dtype=np.float64)
+                m64.sum_duplicates()
+                blocks.append(m64.astype(np.float32))
+        else:
+            zi, yi, xi = np.rint(Z).astype(np.int64), np.rint(Y).astype(np.int64), np.rint(X).astype(np.int64)
+            ok = (zi >= 0) & (zi <= mz - 1) & (yi >= 0) & (yi <= my - 1) & (xi >= 0) & (xi <= mx - 1)
+            idx = np.full(zi.shape, -1, dtype=np.int64)
+            idx[ok] = rank[zi[ok], yi[ok], xi[ok]]   # -1 outside the cylinder
+            hit = idx >= 0                             # [k, j, i]
+            has = hit.any(axis=2)                      # rows exist for rays with at least one sample in the mask
+            row_of = np.cumsum(has.ravel()).reshape(has.shape) - 1
+            kk, jj, _ = np.nonzero(hit)
+            rows = row_of[kk, jj]
+            cols = idx[hit]
+            n_rows = int(has.sum())
+            if n_rows:
+                blocks.append(csr_matrix((np.ones(len(cols), dtype=np.float32), (rows, cols)), shape=(n_rows, n_x),
+                                         dtype=np.float32))   # duplicates add up: an entry is a hit count
         if n_rows:
-            blocks.append(csr_matrix((np.ones(len(cols), dtype=np.float32), (rows, cols)), shape=(n_rows, n_x),
-                                     dtype=np.float32))   # duplicates add up: an entry is a hit count
             k_idx, j_idx = np.nonzero(has)
             bs.append(pixel_vals[j_idx, k_idx].astype(np.float32))
             pids.append((k_idx * ny + j_idx).astype(np.int32))
@@ -191,8 +216,81 @@ def build_A_data_matrix(image, scale2d_to_3d, twist_degree, rise_pixel, csym, ti
     return vstack(blocks).tocsr(), np.concatenate(bs).astype(np.float32), np.concatenate(pids)
 
 
+def _build_A_helical_sym_matrix_linear(nz, ny, nx, twist_degree, rise_pixel, csym, rmin, rmax, min_sym_pairs):
+    """The trilinear branch (solver:910-1140), quirks included: a pair counts only when |dz|, |dy| and |dx| of the two
+    truncated positions are all >= 3; de-duplication by the ROUNDED positions' ranks; the weights of corners 110 and 111
+    are xf*yf*(1-xf) and xf*yf*zf."""
+    pairs = sorted_hsym_csym_pairs(twist_degree, rise_pixel, csym, nz)
+    mask, (Z, Y, X) = get_cylindrical_mask(nz, ny, nx, rmin=rmin, rmax=rmax, return_xyz=True)
+    n_x = int(np.count_nonzero(mask))
+    mz_i, my_i, mx_i = np.nonzero(mask)
+    rank = np.zeros(mask.shape, dtype=np.int64) - 1
+    rank[(mz_i, my_i, mx_i)] = np.arange(n_x)
+    xyz = np.vstack((X.ravel(), Y.ravel(), Z.ravel())).transpose().astype(np.float64)
+    seen = {-1}
+    r_idx, c_idx, vals = [], [], []
+    row_count = 0
+    corners = list(itertools.product((0, 1), (0, 1), (0, 1)))  # (dz, dy, dx): 000, 001, 010, 011, 100, 101, 110, 111
+
+    def weights(zf, yf, xf):
+        return [(1 - zf) * (1 - yf) * (1 - xf), (1 - zf) * (1 - yf) * xf, (1 - zf) * yf * (1 - xf), (1 - zf) * yf * xf,
+                zf * (1 - yf) * (1 - xf), zf * (1 - yf) * xf, xf * yf * (1 - xf), xf * yf * zf]
+
+    for p in pairs:
+        (h_i, c_i), (h_j, c_j) = p[-1]
+
+        def image_of(h, c):
+            t = rot_apply(euler_matrix("z", twist_degree * h + c * 360 / csym), xyz, inverse=False)
+            return (t[:, 0].reshape(mask.shape) + nx // 2, t[:, 1].reshape(mask.shape) + ny // 2,
+                    t[:, 2].reshape(mask.shape) + nz // 2 + rise_pixel * h)
+
+        Xi, Yi, Zi = image_of(h_i, c_i)
+        Xj, Yj, Zj = image_of(h_j, c_j)
+        added = 0
+        for m in range(n_x):
+            k, j, i = mz_i[m], my_i[m], mx_i[m]
+            a = (int(Zi[k, j, i]), int(Yi[k, j, i]), int(Xi[k, j, i]))
+            b = (int(Zj[k, j, i]), int(Yj[k, j, i]), int(Xj[k, j, i]))
+            lim = (nz, ny, nx)
+            if any(not (0 <= a[q] and a[q] + 1 <= lim[q] - 1 and 0 <= b[q] and b[q] + 1 <= lim[q] - 1) for q in range(3)):
+                continue
+            ia = [rank[a[0] + dz, a[1] + dy_, a[2] + dx] for dz, dy_, dx in corners]
+            ib = [rank[b[0] + dz, b[1] + dy_, b[2] + dx] for dz, dy_, dx in corners]
+            if min(ia) < 0 or min(ib) < 0:
+                continue
+            if abs(a[0] - b[0]) < 3 or abs(a[1] - b[1]) < 3 or abs(a[2] - b[2]) < 3:
+                continue
+            ir = rank[round(Zi[k, j, i]), round(Yi[k, j, i]), round(Xi[k, j, i])]
+            jr = rank[round(Zj[k, j, i]), round(Yj[k, j, i]), round(Xj[k, j, i])]
+            pid = int(ir) * n_x + int(jr)
+            if pid in seen:
+                continue
+            seen.add(pid)
+            seen.add(int(jr) * n_x + int(ir))
+            wa = weights(Zi[k, j, i] - a[0], Yi[k, j, i] - a[1], Xi[k, j, i] - a[2])
+            wb = weights(Zj[k, j, i] - b[0], Yj[k, j, i] - b[1], Xj[k, j, i] - b[2])
+            for q in range(8):
+                r_idx.append(row_count + added)
+                c_idx.append(int(ia[q]))
+                vals.append(wa[q])
+            for q in range(8):
+                r_idx.append(row_count + added)
+                c_idx.append(int(ib[q]))
+                vals.append(-wb[q])
+            added += 1
+        row_count += added
+        if row_count >= min_sym_pairs:
+            break
+    if not row_count:
+        return None, None
+    A = csr_matrix((np.asarray(vals, dtype=np.float32), (r_idx, c_idx)), shape=(row_count, n_x), dtype=np.float32)
+    return A, np.zeros(row_count, dtype=np.float32)
+
+
 def build_A_helical_sym_matrix(nz, ny, nx, twist_degree, rise_pixel, csym, rmin, rmax, min_sym_pairs,
                                interpolation="nn"):
+    if interpolation == "linear":
+        return _build_A_helical_sym_matrix_linear(nz, ny, nx, twist_degree, rise_pixel, csym, rmin, rmax, min_sym_pairs)
     assert interpolation == "nn"
     pairs = sorted_hsym_csym_pairs(twist_degree, rise_pixel, csym, nz)
     mask, (Z, Y, X) = get_cylindrical_mask(nz, ny, nx, rmin=rmin, rmax=rmax, return_xyz=True)

@@ -262,6 +262,63 @@ def g5_lsq():
     np.savez_compressed(OUT / "g5_lsq.npz", **arrs)
 
 
+def g4b_path_a_linear():
+    """The trilinear branches of build_A_data_matrix (solver:1414-1503) and build_A_helical_sym_matrix (:910-1140), and
+    lsq_reconstruct(interpolation="linear", model lsq) on the inputs of G4 / G5."""
+    from helicon.webApps.denovo3D import solver_linear_regression as S
+
+    arrs = {}
+    cases = [
+        (np.eye(8, dtype=np.float32), 1.0, 30.0, 2.0, 1, 0.0, 0.0, 0.0, 8, 8, 8, 0, 8, 64),
+        (np.random.default_rng(4).random((12, 16)).astype(np.float32), 1.0, -41.5, 3.7, 2, 3.0, -2.0, 0.5, 10, 14, 10, 2, 6, 300),
+        (np.random.default_rng(5).random((20, 24)).astype(np.float32), 0.8, 27.0, 2.3, 1, 0.0, 0.0, -0.25, 16, 20, 14, 0, 6, 1200),
+    ]
+    fn = getattr(S.build_A_data_matrix, "func", S.build_A_data_matrix)
+    for k, c in enumerate(cases):
+        A, b, pid = fn(*c, "linear", 0, 1)
+        A = A.tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        arrs[f"adata{k}_image"] = c[0]
+        arrs[f"adata{k}_args"] = np.asarray(c[1:], dtype=np.float64)
+        arrs[f"adata{k}_indptr"], arrs[f"adata{k}_indices"], arrs[f"adata{k}_data"] = A.indptr, A.indices, A.data
+        arrs[f"adata{k}_shape"] = np.asarray(A.shape)
+        arrs[f"adata{k}_b"], arrs[f"adata{k}_pid"] = b, pid
+    fn = getattr(S.build_A_helical_sym_matrix, "func", S.build_A_helical_sym_matrix)
+    for k, c in enumerate([(8, 16, 16, 30.0, 2.0, 1, 0.0, 7.0, 200), (6, 20, 20, -41.5, 3.7, 2, 1.0, 9.0, 600)]):
+        A, b = fn(*c, "linear", 0)
+        A = A.tocsr()
+        A.sort_indices()
+        arrs[f"ahsym{k}_args"] = np.asarray(c, dtype=np.float64)
+        arrs[f"ahsym{k}_indptr"], arrs[f"ahsym{k}_indices"], arrs[f"ahsym{k}_data"] = A.indptr, A.indices, A.data
+        arrs[f"ahsym{k}_shape"] = np.asarray(A.shape)
+    np.random.seed(42)
+    img = np.random.rand(12, 12).astype(np.float32)
+    (rec, _, _), score = S.lsq_reconstruct(projection_image=img, scale2d_to_3d=1.0, twist_degree=30.0, rise_pixel=2.0, csym=1,
+                                           reconstruct_diameter_2d_pixel=8, reconstruct_diameter_3d_pixel=8,
+                                           reconstruct_length_2d_pixel=8, reconstruct_length_3d_pixel=8, sym_oversample=1,
+                                           interpolation="linear", algorithm=dict(model="lsq"), cpu=1)
+    arrs.update(seed42_image=img, seed42_rec3d=rec, seed42_score=np.asarray([score]))
+    n, apix = 32, 5.0
+    d, br = 0.4 * n * apix, 2 * apix
+    clean = utils.simulate_helical_projection(1, 29.0, 10.0, 1, d, br, 0, 0, n, n, apix)
+    himg = (clean / clean.max()).astype(np.float32)
+    arrs["helix_image"] = himg
+    tws = np.asarray([25.0, 29.0, 33.0])
+    scores = []
+    for tw in tws:
+        (rec, _, _), sc = S.lsq_reconstruct(projection_image=himg, scale2d_to_3d=1.0, twist_degree=float(tw), rise_pixel=2.0,
+                                            csym=1, reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20,
+                                            reconstruct_length_2d_pixel=32, reconstruct_length_3d_pixel=6, sym_oversample=1,
+                                            interpolation="linear", algorithm=dict(model="lsq"), cpu=1)
+        scores.append(sc)
+        if tw == 29.0:
+            arrs["helix_rec3d_29"] = rec
+    arrs["helix_twists"] = tws
+    arrs["helix_scores"] = np.asarray(scores)
+    np.savez_compressed(OUT / "g4b_path_a_linear.npz", **arrs)
+
+
 def g6_filters():
     rng = np.random.default_rng(6)
     x = rng.normal(size=(32, 32))
@@ -322,6 +379,7 @@ if __name__ == "__main__":
     g3_composed()
     g3b_general_sizes()
     g4_path_a()
+    g4b_path_a_linear()
     g5_lsq()
     g6_filters()
     g7_helical_sym()

@@ -98,3 +98,51 @@ def test_g5_lsq_reconstruct_scores_and_volumes(golden_dir):
         assert score == pytest.approx(float(want), abs=1e-4), tw
         if tw == 29.0:
             assert np.abs(rec - g["helix_rec3d_29"]).max() < 5e-3 * np.abs(g["helix_rec3d_29"]).max()
+
+
+def test_g4b_linear_matrices_and_scores(golden_dir):
+    """Trilinear branch: the data matrix (solver:1414-1503) and the symmetry matrix (:910-1140, weight typos and the
+    |d| >= 3 rule included) have the reference's structure exactly and its float32 entries to an ulp; lsq_reconstruct
+    with interpolation="linear" reproduces the reference's scores."""
+    g = np.load(golden_dir / "g4b_path_a_linear.npz")
+    for k in range(3):
+        a = g[f"adata{k}_args"]
+        Am, b, pid = A.build_A_data_matrix(g[f"adata{k}_image"], a[0], a[1], a[2], int(a[3]), a[4], a[5], a[6], int(a[7]),
+                                           int(a[8]), int(a[9]), int(a[10]), int(a[11]), int(a[12]), "linear")
+        Am.sum_duplicates()
+        Am.sort_indices()
+        ref = _csr(g, f"adata{k}")
+        assert Am.shape == ref.shape
+        np.testing.assert_array_equal(Am.indptr, ref.indptr)
+        np.testing.assert_array_equal(Am.indices, ref.indices)
+        np.testing.assert_allclose(Am.data, ref.data, rtol=2e-7, atol=1e-9)   # float64 sums rounded to float32 once
+        np.testing.assert_array_equal(b, g[f"adata{k}_b"])
+        np.testing.assert_array_equal(pid, g[f"adata{k}_pid"])
+    for k in range(2):
+        a = g[f"ahsym{k}_args"]
+        Am, b = A.build_A_helical_sym_matrix(int(a[0]), int(a[1]), int(a[2]), a[3], a[4], int(a[5]), a[6], a[7], int(a[8]), "linear")
+        Am.sort_indices()
+        ref = _csr(g, f"ahsym{k}")
+        assert Am.shape == ref.shape
+        np.testing.assert_array_equal(Am.indptr, ref.indptr)
+        np.testing.assert_array_equal(Am.indices, ref.indices)
+        np.testing.assert_array_equal(Am.data, ref.data)
+    (rec, _, _), score = A.lsq_reconstruct(g["seed42_image"], 1.0, 30.0, 2.0, 1, reconstruct_diameter_2d_pixel=8,
+                                           reconstruct_diameter_3d_pixel=8, reconstruct_length_2d_pixel=8,
+                                           reconstruct_length_3d_pixel=8, sym_oversample=1, interpolation="linear")
+    # The matrices above are the reference's; what differs is the arithmetic of the solve: the reference runs scipy's
+    # LSMR on float32 operands (float32 vectors and, under NumPy 2's promotion rules, float32 scalar recurrences) and
+    # stops the bounded iteration at tol = 1e-2, the oracle iterates in float64.  With trilinear weights that moves the
+    # cosine score by up to 1e-3 (with 0/1 hit counts, fixture G5, by less than 1e-4).
+    LIN_TOL = 2e-3
+    assert score == pytest.approx(float(g["seed42_score"][0]), abs=LIN_TOL)
+    got = []
+    for tw, want in zip(g["helix_twists"], g["helix_scores"]):
+        (rec, _, _), score = A.lsq_reconstruct(g["helix_image"], 1.0, float(tw), 2.0, 1, reconstruct_diameter_2d_pixel=20,
+                                               reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=32,
+                                               reconstruct_length_3d_pixel=6, sym_oversample=1, interpolation="linear")
+        assert score == pytest.approx(float(want), abs=LIN_TOL), tw
+        got.append(score)
+        if tw == 29.0:
+            assert A.cosine_similarity(rec.ravel(), g["helix_rec3d_29"].ravel()) > 0.995   # same map, loosely converged
+    assert int(np.argmax(got)) == int(np.argmax(g["helix_scores"])) == 1
