@@ -242,6 +242,8 @@ typedef struct hh_pa_params {
       reconstruct_diameter_3d_inner_pixel, reconstruct_length_3d_pixel;
   int64_t min_projection_lines;   /* stop adding symmetry operations once the data rows exceed this (solver:1647) */
   int64_t min_sym_pairs;          /* symmetry rows wanted (solver:1275); 0 = no symmetry block */
+  int32_t interpolation;          /* 0 = "nn" (solver:1511-1553, 1142-1298), 1 = "linear" (solver:1414-1503, 910-1140:
+                                     trilinear weights, rays recomputed in every product, 16-entry symmetry rows) */
 } hh_pa_params;
 int hh_pa_create(hh_pa** out, int device, const float* image, int ny, int nx, const hh_pa_params* params);
 void hh_pa_destroy(hh_pa* pa);
