@@ -68,10 +68,13 @@
 #define HH_KT_KYW 128      // run-table first pass: ky rows per workgroup
 #endif
 #ifndef HH_KF_CPW
-#define HH_KF_CPW 128      // fused pass: candidates per workgroup (of one run) in large launches; 16 in small ones
+#define HH_KF_CPW 0        // fused pass: candidates per workgroup (of one run); 0 = chosen per launch (fused_groups_per_run)
 #endif
 #ifndef HH_FUSED_BATCH
-#define HH_FUSED_BATCH 32768  // fused pass: candidates per launch (whole runs); 1.3 GB of column factors + moments at N = 512
+#define HH_FUSED_BATCH 131072  // fused pass: most candidates per launch (whole runs); 6 GB of column factors + moments at N = 512
+#endif
+#ifndef HH_FUSED_BYTES
+#define HH_FUSED_BYTES (8LL << 30)  // fused pass: the launch is shortened so that its column factors (two halves) fit this
 #endif
 #ifndef HH_SEG_BATCH
 #define HH_SEG_BATCH 1024   // fused pass with several segments: candidates per launch (q and the contraction's partials)
@@ -1494,8 +1497,9 @@ struct FusedArgs {
   int n_kb;
   int batch;              // candidates in this launch
   int run_len;            // candidates per run inside this batch
-  int cpw;                // candidates per workgroup (of one run)
-  int groups_per_run;     // workgroup layers per run: ceil(run_len / cpw)
+  // work layers: the first runs_a runs are cut into groups_a layers of cpw_a candidates each, the remaining runs
+  // into groups_b layers of cpw_b (shorter workgroups for the launch's last, partly filled round: fused_schedule)
+  int runs_a, groups_a, cpw_a, groups_b, cpw_b;
   int cap;                // table rows reserved per run
   int rows_lds;           // table rows staged per ky (>= every run's row count, >= kg)
   int kg;                 // table rows per group of four columns
@@ -1580,10 +1584,21 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
 #endif
   const int kb = a.kb_list ? a.kb_list[kbi] : kbi;
   const int row = kb * 8 + gi;
-  const int run = gy / a.groups_per_run;
-  const int off = (gy % a.groups_per_run) * a.cpw;
+  int run, off, cpw;
+  {
+    const int la = a.runs_a * a.groups_a;
+    if (gy < la) {
+      run = gy / a.groups_a;
+      off = (gy % a.groups_a) * a.cpw_a;
+      cpw = a.cpw_a;
+    } else {
+      run = a.runs_a + (gy - la) / a.groups_b;
+      off = ((gy - la) % a.groups_b) * a.cpw_b;
+      cpw = a.cpw_b;
+    }
+  }
   const int cfirst = run * a.run_len + off;
-  const int nc = min(a.cpw, min(a.run_len - off, a.batch - cfirst));
+  const int nc = min(cpw, min(a.run_len - off, a.batch - cfirst));
   if (nc <= 0) return;
 
   float2 tw[TwN<N>::total];
@@ -2251,6 +2266,9 @@ struct hh_ctx {
   void* comm = nullptr;          // ncclComm_t of hh_comm_init (RCCL, loaded on first use)
   hh_gen* gen = nullptr;
   int max_batch = 0;
+  int n_cu = 0;                  // compute units of the device
+  int slots = 0;                 // resident k_fused_pass workgroups for the launch shape slots_key (fused_slots)
+  size_t slots_key = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
@@ -2715,6 +2733,73 @@ int dispatch_fused_n(hh_ctx* c, const FusedArgs& a, int layers) {
 #undef HH_CALL
 }
 
+// Workgroups of k_fused_pass the device holds at once (occupancy x compute units), for the launch shape in `a`.
+template <int N, int EPI, int LOG>
+int slots_fused(hh_ctx* c, const FusedArgs& a, int* out) {
+  using K = KF<N>;
+  if (int rc = ensure_lds_attr(c, reinterpret_cast<const void*>(&k_fused_pass<N, EPI, LOG>), 160 * 1024)) return rc;
+  int per_cu = 0;
+  HH_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused_pass<N, EPI, LOG>, K::THREADS, K::lds(a.rows_lds, a.kg)));
+  *out = std::max(1, per_cu) * std::max(1, c->n_cu);
+  return HH_OK;
+}
+template <int EPI, int LOG>
+int slots_fused_n(hh_ctx* c, const FusedArgs& a, int* out) {
+#define HH_CALL(NN) slots_fused<NN, EPI, LOG>(c, a, out)
+  HH_SWITCH_N(c, HH_CALL);
+#undef HH_CALL
+}
+int fused_slots(hh_ctx* c, const FusedArgs& a, int* out) {
+  const size_t key = ((size_t)a.rows_lds << 20) ^ ((size_t)a.kg << 8) ^ (size_t)(c->n_segments > 1) ^ ((size_t)c->log_flag << 1);
+  if (c->slots_key == key && c->slots > 0) { *out = c->slots; return HH_OK; }
+  int rc;
+  if (c->n_segments == 1) rc = c->log_flag ? slots_fused_n<EPI_SCORE, 1>(c, a, out) : slots_fused_n<EPI_SCORE, 0>(c, a, out);
+  else rc = c->log_flag ? slots_fused_n<EPI_QSTORE, 1>(c, a, out) : slots_fused_n<EPI_QSTORE, 0>(c, a, out);
+  if (rc == HH_OK) { c->slots = *out; c->slots_key = key; }
+  return rc;
+}
+
+// How the runs of a launch are cut into workgroups.  The grid is (layers of one run) x ky blocks workgroups, `slots`
+// of them resident at a time, each paying a fixed set-up (table slice, weights, twiddles: about four candidates'
+// worth) before its candidates; a launch lasts about ceil(workgroups / slots) x (candidates per workgroup + set-up).
+// Few, long workgroups amortise the set-up, but the last, partly filled round of a launch costs a whole one.  So the
+// runs that fill whole rounds get `groups_a` layers each, and the runs left over for the last round are cut finer
+// (`groups_b`), so that round is short.  C2 in one launch (400 runs of 250, 32 ky blocks, 512 slots) is exactly 25
+// rounds of whole runs; an eighth of it (50 runs) is 3 rounds of whole runs + 2 runs in 8 pieces each, 798 units
+// instead of 4 x 254.
+struct FusedSchedule { int runs_a, groups_a, cpw_a, groups_b, cpw_b, layers; };
+FusedSchedule fused_schedule(int64_t runs, int run_len, int n_kb, int slots) {
+  const int setup = 4, min_cpw = 16, gmax = std::max(1, run_len / min_cpw);
+  auto cpw_of = [&](int g) { return (run_len + g - 1) / g; };
+  auto groups_of = [&](int cpw) { return (run_len + cpw - 1) / cpw; };   // even groups: ceil(len / ceil(len / g)) <= g
+  FusedSchedule best{};
+  double best_t = 1e300;
+  const int g_lo = HH_KF_CPW > 0 ? groups_of(HH_KF_CPW) : 1, g_hi = HH_KF_CPW > 0 ? g_lo : gmax;
+  for (int ga = g_lo; ga <= g_hi; ++ga) {
+    const int cpw_a = cpw_of(ga), ga_e = groups_of(cpw_a);
+    const int64_t per_run = (int64_t)ga_e * n_kb;
+    const int64_t full = runs * per_run / slots;                          // whole rounds of region A
+    const int64_t runs_a = HH_KF_CPW > 0 ? runs : std::min<int64_t>(runs, full * slots / per_run);
+    const int64_t runs_b = runs - runs_a;
+    const double ta = (double)((runs_a * per_run + slots - 1) / slots) * (cpw_a + setup);
+    int gb = ga_e, cpw_b = cpw_a;
+    double tb = 0;
+    if (runs_b > 0) {
+      tb = 1e300;
+      for (int g = ga; g <= gmax; ++g) {
+        const int cw = cpw_of(g), ge = groups_of(cw);
+        const double t = (double)((runs_b * ge * n_kb + slots - 1) / slots) * (cw + setup);
+        if (t < tb * 0.995) { tb = t; gb = ge; cpw_b = cw; }
+      }
+    }
+    if (ta + tb < best_t * 0.995) {  // (near-ties go to the fewer, longer workgroups)
+      best_t = ta + tb;
+      best = FusedSchedule{(int)runs_a, ga_e, cpw_a, gb, cpw_b, (int)(runs_a * ga_e + runs_b * gb)};
+    }
+  }
+  return best;
+}
+
 int dispatch_fused(hh_ctx* c, const FusedArgs& a, int layers) {
   if (c->n_segments == 1) return c->log_flag ? dispatch_fused_n<EPI_SCORE, 1>(c, a, layers) : dispatch_fused_n<EPI_SCORE, 0>(c, a, layers);
   return c->log_flag ? dispatch_fused_n<EPI_QSTORE, 1>(c, a, layers) : dispatch_fused_n<EPI_QSTORE, 0>(c, a, layers);
@@ -2744,8 +2829,9 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   const int nky = c->n / 2;
   // The fused pass has no intermediate to hold, so its batches are not tied to max_batch: long
   // launches even out the tail of the grid (C2: 3.2 M candidates/s at 250 per launch, 3.8 M at 4000).
+  const int fused_cap = (int)std::max<int64_t>(1024, std::min<int64_t>(HH_FUSED_BATCH, HH_FUSED_BYTES / ((int64_t)2 * std::max(1, plan.kg) * c->n * 4)));
   const int bmax = !plan.fused ? c->max_batch
-                   : c->n_segments == 1 ? std::max(c->max_batch, HH_FUSED_BATCH) : std::max(c->max_batch, HH_SEG_BATCH);
+                   : c->n_segments == 1 ? std::max(c->max_batch, fused_cap) : std::max(c->max_batch, HH_SEG_BATCH);
   const int64_t per_batch = plan.len <= bmax ? bmax / plan.len : 1;
   const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
   int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
@@ -2880,25 +2966,27 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       fu.n_kb = c->n_kb;
       fu.batch = bt.nb;
       fu.run_len = bt.run_len;
-      // candidates per workgroup: many amortise the slice and weight loads (C2: +3 % at 64 over 16), but a launch
-      // needs a few rounds of workgroups to fill the chip evenly
-      {
-        const int64_t runs_b = (bt.nb + fu.run_len - 1) / fu.run_len;
-        fu.cpw = HH_KF_CPW;
-        while (fu.cpw > 16 && runs_b * ((fu.run_len + fu.cpw - 1) / fu.cpw) * c->n_kb < 4096) fu.cpw /= 2;
-      }
-      fu.groups_per_run = (fu.run_len + fu.cpw - 1) / fu.cpw;
       fu.cap = plan.rows;
       fu.rows_lds = plan.rows_f;
       fu.kg = plan.kg;
+      int work_layers = 0;
+      {
+        const int64_t runs_b = (bt.nb + fu.run_len - 1) / fu.run_len;
+        const int len = std::min(fu.run_len, bt.nb);
+        int slots = 0;
+        rc = fused_slots(c, fu, &slots);
+        if (rc) return rc;
+        const FusedSchedule fs = fused_schedule(runs_b, len, c->n_kb, slots);
+        fu.runs_a = fs.runs_a; fu.groups_a = fs.groups_a; fu.cpw_a = fs.cpw_a; fu.groups_b = fs.groups_b; fu.cpw_b = fs.cpw_b;
+        work_layers = fs.layers;
+      }
       fu.n_units = c->geom.n_units;
       fu.fin = pending;
       if (bi + 1 < batches.size()) {
         fu.next = factor_args(batches[bi + 1], half ^ 1);
         fu.factor_layers = (fu.next.count + c->n_kb - 1) / c->n_kb;
       }
-      const int runs_here = (bt.nb + fu.run_len - 1) / fu.run_len;
-      rc = dispatch_fused(c, fu, runs_here * fu.groups_per_run);
+      rc = dispatch_fused(c, fu, work_layers);
       if (rc) return rc;
       pending = FinArgs{};
       rc = scores_tail(c, g, first_cand + bt.g0, bt.nb, bi + 1 == batches.size(), d_scores, pending, part);
@@ -3131,6 +3219,7 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
     if (e__ != hipSuccess) return bail(HH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
   HH_CREATE_HIP(hipSetDevice(device));
+  HH_CREATE_HIP(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
   HH_CREATE_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   if (general) {  // runtime-sized kernels; buffers grow with the sweeps
