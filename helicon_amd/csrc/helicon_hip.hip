@@ -1194,6 +1194,37 @@ __device__ __forceinline__ float group_sum(float v) {
   }
 }
 
+// Three sums at once.  For a full wavefront the two cross-row steps are written out as v_add_f32_dpp with a row mask
+// (one instruction each: the compiler's own lowering of the masked update is a zero fill, a v_mov_b32_dpp and an
+// add), interleaved so that no value is read by a DPP instruction less than two instructions after it was written.
+template <int TL>
+__device__ __forceinline__ void group_sum3(float& a, float& b, float& c) {
+  if constexpr (TL == 64) {
+#define HH_DPP_ADD3(CTRL)                                                                               \
+  a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, false));        \
+  b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), CTRL, 0xF, 0xF, false));        \
+  c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), CTRL, 0xF, 0xF, false))
+    HH_DPP_ADD3(0xB1);   // quad_perm [1,0,3,2]
+    HH_DPP_ADD3(0x4E);   // quad_perm [2,3,0,1]
+    HH_DPP_ADD3(0x141);  // row_half_mirror
+    HH_DPP_ADD3(0x140);  // row_mirror: every lane of a row holds the row's sum
+#undef HH_DPP_ADD3
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"   // rows 1, 3: R0+R1, R2+R3
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"   // rows 2, 3: lane 63 = R0+R1+R2+R3
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c));
+  } else {
+    a = group_sum<TL>(a);
+    b = group_sum<TL>(b);
+    c = group_sum<TL>(c);
+  }
+}
+
 // A workgroup owns ONE ky block (8 spectrum rows, one per transform group) and walks CPW candidates:
 // the rows' mask weights and centred reference values are loaded once into registers and serve all
 // of them, so the second pass reads the weight table once per 16 candidates instead of once per
@@ -1328,12 +1359,8 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
           }
         }
         if constexpr (EPI != EPI_STORE) {
-          a1 = group_sum<TL>(a1);
-          a2 = group_sum<TL>(a2);
-          a3 = group_sum<TL>(a3);
-          n1 = group_sum<TL>(n1);
-          n2 = group_sum<TL>(n2);
-          n3 = group_sum<TL>(n3);
+          group_sum3<TL>(a1, a2, a3);
+          group_sum3<TL>(n1, n2, n3);
           if (writer) {
             double* const o = a.partials + (b * K::NPART + wave_in_row) * 3;
             o[0] = a1;
@@ -1363,9 +1390,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD :
         else
           s3 += w[m].y * q;
       }
-      s1 = group_sum<TL>(s1);
-      s2 = group_sum<TL>(s2);
-      s3 = group_sum<TL>(s3);
+      group_sum3<TL>(s1, s2, s3);
       if (writer) {
         double* const o = a.partials + (b * K::NPART + (size_t)row * K::WPR + wave_in_row) * 3;
         o[0] = s1;
@@ -1473,7 +1498,7 @@ __device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b, fl
   if (x < 4) cgo[N / 4 + x] = *kc_s;
 #if HH_POISON
   // sanitizer build: factor rows past the candidate's row count must never be read by the fused pass
-  for (int k = *kc_s; k < a.kg; ++k) a.eg[((size_t)b * a.kg + k) * N + x] = __builtin_nanf("");
+  for (int k = max(*kc_s, 1); k < a.kg; ++k) a.eg[((size_t)b * a.kg + k) * N + x] = __builtin_nanf("");
 #endif
 }
 
@@ -1637,6 +1662,11 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     if (tid < CGS) cgs[tid] = a.cgs[(size_t)b * CGS + tid];
   };
   stage_factors(cfirst);  // buffer 0
+  // Every load issued so far (twiddles, weights, slice, factors) is retired HERE, explicitly: the barrier's fence only
+  // waits for LDS traffic, and with register loads still pending at the loop's entry the compiler guards their first
+  // uses INSIDE the loop with counted waits — the last of them a vmcnt(0) in the middle of part B, which in every later
+  // round drains the LDS-DMA copies that are meant to fly until the round's end.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
   __syncthreads();
 
   const int wave_in_row = T > 64 ? (t >> 6) : 0;
@@ -1670,25 +1700,37 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       const float* const erow1 = egc + 4 * xg1;
       // table rows this candidate needs (<= kg; a wave-uniform LDS word written by the factor kernel)
       // (clamped to the buffer's kg: whatever the word holds, the walk is bounded)
-      const int kgn = (HH_ABLATE & 2048) ? 0 : max(0, min(a.kg, __builtin_amdgcn_readfirstlane(cgc[N / 4])));
-      float2 p0 = make_float2(0.f, 0.f), p1 = p0, p2 = p0, p3 = p0, q0 = p0, q1 = p0, q2 = p0, q3 = p0;
-      float2 ga = grow0[0], gb = grow1[0];
-      float4 ea = *reinterpret_cast<const float4*>(erow0), eb = *reinterpret_cast<const float4*>(erow1);
+      // (at least one: a candidate that reaches no column has a first factor row of zeros, so the sums need no
+      // separate zero fill)
+      const int kgn = (HH_ABLATE & 2048) ? 0 : max(1, min(a.kg, __builtin_amdgcn_readfirstlane(cgc[N / 4])));
+      // The first table row initialises the sums (no zero fill), the others accumulate; the operand addresses are
+      // base + k x constant, so the unrolled loop addresses them with instruction offsets.
+      float2 p0, p1, p2, p3, q0, q1, q2, q3;
+      if (!(HH_ABLATE & 2048)) {
+        {
+          const float2 ga = grow0[0], gb = grow1[0];
+          const float4 ea = *reinterpret_cast<const float4*>(erow0), eb = *reinterpret_cast<const float4*>(erow1);
+          p0 = make_float2(ea.x * ga.x, ea.x * ga.y); p1 = make_float2(ea.y * ga.x, ea.y * ga.y);
+          p2 = make_float2(ea.z * ga.x, ea.z * ga.y); p3 = make_float2(ea.w * ga.x, ea.w * ga.y);
+          q0 = make_float2(eb.x * gb.x, eb.x * gb.y); q1 = make_float2(eb.y * gb.x, eb.y * gb.y);
+          q2 = make_float2(eb.z * gb.x, eb.z * gb.y); q3 = make_float2(eb.w * gb.x, eb.w * gb.y);
+        }
 #pragma unroll 2
-      for (int k = 0; k < kgn; ++k) {
-        const int kn = min(k + 1, kgn - 1);  // the last iteration re-reads its own row: nothing past the buffers
-        const float2 gan = grow0[kn], gbn = grow1[kn];
-        const float4 ean = *reinterpret_cast<const float4*>(erow0 + (size_t)kn * N);
-        const float4 ebn = *reinterpret_cast<const float4*>(erow1 + (size_t)kn * N);
-        p0.x = fmaf(ea.x, ga.x, p0.x); p0.y = fmaf(ea.x, ga.y, p0.y);
-        p1.x = fmaf(ea.y, ga.x, p1.x); p1.y = fmaf(ea.y, ga.y, p1.y);
-        p2.x = fmaf(ea.z, ga.x, p2.x); p2.y = fmaf(ea.z, ga.y, p2.y);
-        p3.x = fmaf(ea.w, ga.x, p3.x); p3.y = fmaf(ea.w, ga.y, p3.y);
-        q0.x = fmaf(eb.x, gb.x, q0.x); q0.y = fmaf(eb.x, gb.y, q0.y);
-        q1.x = fmaf(eb.y, gb.x, q1.x); q1.y = fmaf(eb.y, gb.y, q1.y);
-        q2.x = fmaf(eb.z, gb.x, q2.x); q2.y = fmaf(eb.z, gb.y, q2.y);
-        q3.x = fmaf(eb.w, gb.x, q3.x); q3.y = fmaf(eb.w, gb.y, q3.y);
-        ga = gan; gb = gbn; ea = ean; eb = ebn;
+        for (int k = 1; k < kgn; ++k) {
+          const float2 ga = grow0[k], gb = grow1[k];
+          const float4 ea = *reinterpret_cast<const float4*>(erow0 + (size_t)k * N);
+          const float4 eb = *reinterpret_cast<const float4*>(erow1 + (size_t)k * N);
+          p0.x = fmaf(ea.x, ga.x, p0.x); p0.y = fmaf(ea.x, ga.y, p0.y);
+          p1.x = fmaf(ea.y, ga.x, p1.x); p1.y = fmaf(ea.y, ga.y, p1.y);
+          p2.x = fmaf(ea.z, ga.x, p2.x); p2.y = fmaf(ea.z, ga.y, p2.y);
+          p3.x = fmaf(ea.w, ga.x, p3.x); p3.y = fmaf(ea.w, ga.y, p3.y);
+          q0.x = fmaf(eb.x, gb.x, q0.x); q0.y = fmaf(eb.x, gb.y, q0.y);
+          q1.x = fmaf(eb.y, gb.x, q1.x); q1.y = fmaf(eb.y, gb.y, q1.y);
+          q2.x = fmaf(eb.z, gb.x, q2.x); q2.y = fmaf(eb.z, gb.y, q2.y);
+          q3.x = fmaf(eb.w, gb.x, q3.x); q3.y = fmaf(eb.w, gb.y, q3.y);
+        }
+      } else {
+        p0 = p1 = p2 = p3 = q0 = q1 = q2 = q3 = make_float2(0.f, 0.f);
       }
       // The row is handed to the transform through the group's exchange buffer.  A lane stores 2 x 32 bytes at a
       // 32-byte lane stride: the eight lanes of a ds_write_b128 group would hit four bank groups twice, so the
@@ -1760,12 +1802,8 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
             n3 += wnm.y * qn;
           }
         }
-        a1 = group_sum<TL>(a1);
-        a2 = group_sum<TL>(a2);
-        a3 = group_sum<TL>(a3);
-        n1 = group_sum<TL>(n1);
-        n2 = group_sum<TL>(n2);
-        n3 = group_sum<TL>(n3);
+        group_sum3<TL>(a1, a2, a3);
+        group_sum3<TL>(n1, n2, n3);
         if (writer) {
           double* const o = a.partials + (b * KP::NPART + wave_in_row) * 3;
           o[0] = a1;
@@ -1792,9 +1830,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         else
           s3 += w[m].y * q;
       }
-      s1 = group_sum<TL>(s1);
-      s2 = group_sum<TL>(s2);
-      s3 = group_sum<TL>(s3);
+      group_sum3<TL>(s1, s2, s3);
       if (writer) {
         double* const o = a.partials + (b * KP::NPART + (size_t)row * KP::WPR + wave_in_row) * 3;
         o[0] = s1;
@@ -1829,8 +1865,8 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     if (!late) part_b(it);
     // The LDS-DMA copies of the next candidate's factors count on vmcnt only; neither the workgroup-scope fence nor
     // s_barrier waits for them, so every wavefront retires its own copies before it arrives at the barrier.
-    if (more) lds_dma_wait();
-    __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
+    if (more && !(HH_ABLATE & 32768)) lds_dma_wait();
+    if (!(HH_ABLATE & 16384)) __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
   }
   if (late) part_b(nc - 1);
 }
