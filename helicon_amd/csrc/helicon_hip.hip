@@ -97,6 +97,9 @@
 #ifndef HH_KF_CUT
 #define HH_KF_CUT 1        // fused pass: part A of a candidate ends after the butterflies of this transform stage
 #endif
+#ifndef HH_KF_SPLIT
+#define HH_KF_SPLIT 1      // fused pass, N = 1024: one radix-2 step across a row's two wavefronts, then a 512-point
+#endif                     // transform inside each (one workgroup barrier per candidate instead of six)
 #ifndef HH_KF_PRIO
 #define HH_KF_PRIO 0       // fused pass: s_setprio level of the late wavefronts (0 = off)
 #endif
@@ -201,7 +204,8 @@ template <int N> struct TwN {
 
 // Twiddles depend on the lane only, so a lane fetches them once (from a float64-rounded table
 // W_N[k] = exp(-2 pi i k / N)) and keeps them in registers across all its transforms.
-template <int N, int R, int NS, int OFF>
+// (TS: the table is W_{N TS}, every TS-th entry of it is W_N)
+template <int N, int R, int NS, int OFF, int TS = 1>
 __device__ __forceinline__ void load_stage_twiddles(float2* tw, int t, const float2* __restrict__ table) {
   constexpr int T = N / 8, NB = 8 / R;
 #pragma unroll
@@ -209,16 +213,16 @@ __device__ __forceinline__ void load_stage_twiddles(float2* tw, int t, const flo
     const int j = t + q * T;
     const int k = j & (NS - 1);
 #pragma unroll
-    for (int r = 1; r < R; ++r) tw[OFF + q * (R - 1) + (r - 1)] = table[(r * k * (N / (NS * R))) & (N - 1)];
+    for (int r = 1; r < R; ++r) tw[OFF + q * (R - 1) + (r - 1)] = table[((r * k * (N / (NS * R))) & (N - 1)) * TS];
   }
 }
 
-template <int N>
+template <int N, int TS = 1>
 __device__ __forceinline__ void load_twiddles(float2 (&tw)[TwN<N>::total], int t, const float2* __restrict__ table) {
   using P = Plan<N>;
-  load_stage_twiddles<N, P::r1, P::r0, TwN<N>::off1>(tw, t, table);
-  if constexpr (P::n > 2) load_stage_twiddles<N, P::r2, P::r0 * P::r1, TwN<N>::off2>(tw, t, table);
-  if constexpr (P::n > 3) load_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::off3>(tw, t, table);
+  load_stage_twiddles<N, P::r1, P::r0, TwN<N>::off1, TS>(tw, t, table);
+  if constexpr (P::n > 2) load_stage_twiddles<N, P::r2, P::r0 * P::r1, TwN<N>::off2, TS>(tw, t, table);
+  if constexpr (P::n > 3) load_stage_twiddles<N, P::r3, P::r0 * P::r1 * P::r2, TwN<N>::off3, TS>(tw, t, table);
 }
 
 // Where a lane finds its twiddles: its own registers (K_B keeps them across all its rows) or a
@@ -1626,13 +1630,30 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   const int nc = min(cpw, min(a.run_len - off, a.batch - cfirst));
   if (nc <= 0) return;
 
-  float2 tw[TwN<N>::total];
-  load_twiddles<N>(tw, t, a.twtab);
+  // N = 1024 (SPLIT): a row belongs to two wavefronts (h = 0, 1).  A lane's build already owns columns n and n + N/2
+  // (its two groups of four), so the first radix-2 step of the row transform needs no exchange:
+  //   y0[n] = x[n] + x[n + N/2],  y1[n] = (x[n] - x[n + N/2]) W_N^n,   X[2k] = DFT_{N/2}(y0)[k],  X[2k + 1] = DFT_{N/2}(y1)[k].
+  // Wavefront h then transforms y_h (N/2 = 512 points, exchanges inside the wavefront, no workgroup barrier) and
+  // scores the bins kx = 2k + h.  One workgroup barrier per candidate (both wavefronts write both halves) replaces
+  // the six of the 8 x 8 x 8 x 2 plan, whose every exchange crossed the two wavefronts.
+  constexpr bool SPLIT = HH_KF_SPLIT && N == 1024;
+  constexpr int NF = SPLIT ? N / 2 : N, TF = NF / 8;   // transform length and lanes of one transform
+  const int h = SPLIT ? (t >> 6) : 0, tf = SPLIT ? (t & 63) : t;
+  float2* const fbuf = SPLIT ? buf + h * (NF + 2) : buf;   // the wavefront's half of the row's panel (16-byte aligned)
+  const int wl = SPLIT ? 2 * tf + h : t;   // the lane's slot in a weight row: bins kx = wl + m T  (SPLIT: 2 (tf + 64 m) + h)
+
+  float2 tw[TwN<NF>::total];
+  load_twiddles<NF, N / NF>(tw, tf, a.twtab);
   const TwRegs twsrc{tw};
+  float2 r2tw[SPLIT ? 4 : 1];  // SPLIT: W_N^(4 t + c)
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r2tw[c] = a.twtab[4 * t + c];
+  }
 
   float2 w[8];  // this row's weights {w, w (E - Ebar)} for the lane's 8 bins, kept for all candidates
   {
-    const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + t) * 8);
+    const float4* const wrow = reinterpret_cast<const float4*>(a.w2 + ((size_t)row * T + wl) * 8);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const float4 q = wrow[m];
@@ -1681,7 +1702,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   // registers between A and B, and the factor buffers are used exactly as without the stagger: A(it) reads buffer
   // it & 1 in round it, the copies for it + 1 go to the other buffer, one workgroup barrier closes the round.
   constexpr bool STAGGER = HH_KF_STAGGER && T == 64;
-  constexpr int KCUT = (HH_KF_CUT < Plan<N>::n) ? HH_KF_CUT : 1;  // A ends at the exchange after this stage
+  constexpr int KCUT = (HH_KF_CUT < Plan<NF>::n) ? HH_KF_CUT : 1;  // A ends at the exchange after this stage
   const bool late = STAGGER && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4;
   if (HH_KF_PRIO && late) __builtin_amdgcn_s_setprio(HH_KF_PRIO);
 
@@ -1736,16 +1757,33 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       // 32-byte lane stride: the eight lanes of a ds_write_b128 group would hit four bank groups twice, so the
       // 16-byte chunk c = x / 2 lives at c ^ ((c >> 3) & 1) (chunks 2 xg, 2 xg + 1 of lanes xg and xg + 4 then fall
       // into different halves of the 128-byte bank span); the reader un-swizzles with one precomputed base.
-      float4* const row4 = reinterpret_cast<float4*>(buf);
       auto chunk = [](int c) { return HH_KF_PSWZ ? (c ^ ((c >> 3) & 1)) : c; };
-      row4[chunk(2 * xg0)] = make_float4(p0.x, p0.y, p1.x, p1.y);
-      row4[chunk(2 * xg0 + 1)] = make_float4(p2.x, p2.y, p3.x, p3.y);
-      row4[chunk(2 * xg1)] = make_float4(q0.x, q0.y, q1.x, q1.y);
-      row4[chunk(2 * xg1 + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
+      if constexpr (SPLIT) {
+        // the radix-2 step, then y0 into the row's first half and y1 into its second (chunks 2 t, 2 t + 1 of each)
+        const float2 d0 = csub(p0, q0), d1 = csub(p1, q1), d2 = csub(p2, q2), d3 = csub(p3, q3);
+        p0 = cadd(p0, q0); p1 = cadd(p1, q1); p2 = cadd(p2, q2); p3 = cadd(p3, q3);
+        q0 = cmul(d0, r2tw[0]); q1 = cmul(d1, r2tw[1]); q2 = cmul(d2, r2tw[2]); q3 = cmul(d3, r2tw[3]);
+        float4* const y0 = reinterpret_cast<float4*>(buf);
+        float4* const y1 = reinterpret_cast<float4*>(buf + NF + 2);
+        y0[chunk(2 * t)] = make_float4(p0.x, p0.y, p1.x, p1.y);
+        y0[chunk(2 * t + 1)] = make_float4(p2.x, p2.y, p3.x, p3.y);
+        y1[chunk(2 * t)] = make_float4(q0.x, q0.y, q1.x, q1.y);
+        y1[chunk(2 * t + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
+      } else {
+        float4* const row4 = reinterpret_cast<float4*>(buf);
+        row4[chunk(2 * xg0)] = make_float4(p0.x, p0.y, p1.x, p1.y);
+        row4[chunk(2 * xg0 + 1)] = make_float4(p2.x, p2.y, p3.x, p3.y);
+        row4[chunk(2 * xg1)] = make_float4(q0.x, q0.y, q1.x, q1.y);
+        row4[chunk(2 * xg1 + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
+      }
     }
     group_sync<T>();
     float2 v[8];
-    if constexpr (HH_KF_PSWZ && T % 32 == 0) {  // x = t + m T: bit 4 of x is bit 4 of t, one swizzled base serves every m
+    if constexpr (SPLIT) {  // n = tf + 64 m of the wavefront's own half
+      const int ps = HH_KF_PSWZ ? ((((tf >> 1) ^ ((tf >> 4) & 1)) << 1) | (tf & 1)) : tf;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = fbuf[ps + m * TF];
+    } else if constexpr (HH_KF_PSWZ && T % 32 == 0) {  // x = t + m T: bit 4 of x is bit 4 of t, one swizzled base serves every m
       const int ps = (((t >> 1) ^ ((t >> 4) & 1)) << 1) | (t & 1);
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = buf[ps + m * T];
@@ -1756,36 +1794,37 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         v[m] = buf[HH_KF_PSWZ ? ((((x >> 1) ^ ((x >> 4) & 1)) << 1) | (x & 1)) : x];
       }
     }
-    if constexpr (T > 64) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
-    if (!(HH_ABLATE & 16)) fft_lanes_part<N, HH_FFT_SWZ != 0, TwRegs, 1, KCUT>(v, twsrc, t, buf);
+    if constexpr (T > 64 && !SPLIT) __syncthreads();  // both wavefronts of a row have read it before either exchanges in it
+    if (!(HH_ABLATE & 16)) fft_lanes_part<NF, HH_FFT_SWZ != 0, TwRegs, 1, KCUT>(v, twsrc, tf, fbuf);
   };
 
   auto part_b = [&](int cc) {
     const size_t b = (size_t)(cfirst + cc);
     float2 v[8];
     if (!(HH_ABLATE & 16)) {
-      fft_lanes_part<N, HH_FFT_SWZ != 0, TwRegs, 2, KCUT>(v, twsrc, t, buf);  // v[m] = C[kx = t + m*T]; the exchanges reuse the row's panel slots
+      fft_lanes_part<NF, HH_FFT_SWZ != 0, TwRegs, 2, KCUT>(v, twsrc, tf, fbuf);  // v[m] = C[kx = t + m*T] (SPLIT: kx = 2 (tf + 64 m) + h); the exchanges reuse the row's panel slots
     } else {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = buf[t + m * T];
+      for (int m = 0; m < 8; ++m) v[m] = fbuf[tf + m * TF];
     }
 
     bool scored = false;
-    if (kb == 0 && (gi == 0 || T > 64)) {
+    if (kb == 0 && (gi == 0 || (T > 64 && !SPLIT))) {
       // Row 0 of H packs two real sequences (see k_second_pass): un-pack into ky = 0 and ky = N/2
 #pragma unroll
-      for (int m = 0; m < 8; ++m) buf[t + m * T] = v[m];
-      group_sync<T>();
+      for (int m = 0; m < 8; ++m) fbuf[tf + m * TF] = v[m];
+      group_sync<TF>();
       if (gi == 0) {
         // the packed row also carries ky = N/2: its weights come from L2 here (one wavefront in 256)
-        const float2* const nrow = a.w2 + ((size_t)(N / 2) * T + t) * 8;
+        const float2* const nrow = a.w2 + ((size_t)(N / 2) * T + wl) * 8;
         float a1 = 0.f, a2 = 0.f, a3 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const float2 wnm = nrow[m];
-          const int kx = t + m * T;
+          const int kx = SPLIT ? 2 * (tf + m * TF) + h : t + m * T;
           const float2 ck = v[m];
-          const float2 cm = buf[(N - kx) & (N - 1)];
+          // C[N - kx]: the same parity as kx, so (SPLIT) it is in this wavefront's half, at k' = NF - k - h (mod NF)
+          const float2 cm = SPLIT ? fbuf[(NF - (tf + m * TF) - h) & (NF - 1)] : buf[(N - kx) & (N - 1)];
           const float2 f0 = make_float2(0.5f * (ck.x + cm.x), 0.5f * (ck.y - cm.y));
           const float2 fn = make_float2(0.5f * (ck.y + cm.y), -0.5f * (ck.x - cm.x));
           const float q0 = amp_to_q<LOG>(f0), qn = amp_to_q<LOG>(fn);
@@ -1826,7 +1865,7 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         s1 += w[m].x * q;
         s2 += w[m].x * q * q;
         if constexpr (EPI == EPI_QSTORE)
-          qrow[t + m * T] = w[m].x > 0.f ? q : 0.f;
+          qrow[SPLIT ? 2 * (tf + m * TF) + h : t + m * T] = w[m].x > 0.f ? q : 0.f;
         else
           s3 += w[m].y * q;
       }
