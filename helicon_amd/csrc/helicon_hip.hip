@@ -1564,8 +1564,9 @@ struct KF {
   static constexpr int THREADS = N;
   static constexpr int BROW = N + 4;               // complex slots per panel row (+32 B against bank conflicts)
   static constexpr size_t LDS_BUF = (size_t)8 * BROW * sizeof(float2);
+  static constexpr size_t LDS_R2 = (HH_KF_SPLIT && N == 1024) ? (size_t)(N / 2) * sizeof(float2) : 0;  // W_N^n, n < N/2
   static size_t lds(int rows_lds, int kg) {
-    return LDS_BUF + (size_t)8 * rows_lds * sizeof(float2) + 2 * ((size_t)kg * N * sizeof(float) + (size_t)cgs_stride<N>() * sizeof(int));
+    return LDS_BUF + (size_t)8 * rows_lds * sizeof(float2) + 2 * ((size_t)kg * N * sizeof(float) + (size_t)cgs_stride<N>() * sizeof(int)) + LDS_R2;
   }
 };
 
@@ -1645,10 +1646,11 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   float2 tw[TwN<NF>::total];
   load_twiddles<NF, N / NF>(tw, tf, a.twtab);
   const TwRegs twsrc{tw};
-  float2 r2tw[SPLIT ? 4 : 1];  // SPLIT: W_N^(4 t + c)
+  // SPLIT: the radix-2 step's twiddles W_N^n (n < N/2) live in LDS (a lane reads its four per candidate: registers
+  // are what this kernel is short of)
+  float2* const r2tab = reinterpret_cast<float2*>(cgs + 2 * CGS);
   if constexpr (SPLIT) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r2tw[c] = a.twtab[4 * t + c];
+    for (int e = tid; e < N / 2; e += K::THREADS) r2tab[e] = a.twtab[e];
   }
 
   float2 w[8];  // this row's weights {w, w (E - Ebar)} for the lane's 8 bins, kept for all candidates
@@ -1762,7 +1764,9 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         // the radix-2 step, then y0 into the row's first half and y1 into its second (chunks 2 t, 2 t + 1 of each)
         const float2 d0 = csub(p0, q0), d1 = csub(p1, q1), d2 = csub(p2, q2), d3 = csub(p3, q3);
         p0 = cadd(p0, q0); p1 = cadd(p1, q1); p2 = cadd(p2, q2); p3 = cadd(p3, q3);
-        q0 = cmul(d0, r2tw[0]); q1 = cmul(d1, r2tw[1]); q2 = cmul(d2, r2tw[2]); q3 = cmul(d3, r2tw[3]);
+        const float4 wa = *reinterpret_cast<const float4*>(r2tab + 4 * t), wb = *reinterpret_cast<const float4*>(r2tab + 4 * t + 2);
+        q0 = cmul(d0, make_float2(wa.x, wa.y)); q1 = cmul(d1, make_float2(wa.z, wa.w));
+        q2 = cmul(d2, make_float2(wb.x, wb.y)); q3 = cmul(d3, make_float2(wb.z, wb.w));
         float4* const y0 = reinterpret_cast<float4*>(buf);
         float4* const y1 = reinterpret_cast<float4*>(buf + NF + 2);
         y0[chunk(2 * t)] = make_float4(p0.x, p0.y, p1.x, p1.y);
@@ -1777,7 +1781,8 @@ __global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         row4[chunk(2 * xg1 + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
       }
     }
-    group_sync<T>();
+    group_sync<T>();  // (SPLIT: the one workgroup barrier of the transform; an LDS-counter meeting of just the row's two
+                      // wavefronts was tried and lost 3.5 %)
     float2 v[8];
     if constexpr (SPLIT) {  // n = tf + 64 m of the wavefront's own half
       const int ps = HH_KF_PSWZ ? ((((tf >> 1) ^ ((tf >> 4) & 1)) << 1) | (tf & 1)) : tf;
