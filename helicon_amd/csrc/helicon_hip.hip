@@ -77,7 +77,10 @@
 #define HH_FUSED_BYTES (8LL << 30)  // fused pass: the launch is shortened so that its column factors (two halves) fit this
 #endif
 #ifndef HH_SEG_BATCH
-#define HH_SEG_BATCH 1024   // fused pass with several segments: candidates per launch (q and the contraction's partials)
+#define HH_SEG_BATCH 24576  // fused pass with several segments: most candidates per launch (C5: 11.6 ms at 1024, 9.5 ms at 20k)
+#endif
+#ifndef HH_SEG_BYTES
+#define HH_SEG_BYTES (12LL << 30)  // ... shortened so that the batch's masked q (0.5 MB per candidate at N = 512) fits this
 #endif
 #ifndef HH_KF_WPS
 #define HH_KF_WPS 4        // fused pass: waves per SIMD the register allocator must leave room for
@@ -2901,6 +2904,12 @@ int ensure_partials(hh_ctx* c, int batch) {
   return HH_OK;
 }
 
+// several segments: candidates per launch of the shared-twist pipelines (q of a batch lives in HBM)
+inline int seg_batch(int n) {
+  const int64_t per = (int64_t)(n / 2 + 1) * n * (int64_t)sizeof(float);
+  return (int)std::max<int64_t>(1024, std::min<int64_t>(HH_SEG_BATCH, HH_SEG_BYTES / per) / 64 * 64);
+}
+
 // Candidates [first, first + count) of the list of g (count = whole runs of plan.len).
 int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, const RunPlan& plan, int64_t first_cand,
                int64_t count_cand) {
@@ -2911,7 +2920,7 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   // launches even out the tail of the grid (C2: 3.2 M candidates/s at 250 per launch, 3.8 M at 4000).
   const int fused_cap = (int)std::max<int64_t>(1024, std::min<int64_t>(HH_FUSED_BATCH, HH_FUSED_BYTES / ((int64_t)2 * std::max(1, plan.kg) * c->n * 4)));
   const int bmax = !plan.fused ? c->max_batch
-                   : c->n_segments == 1 ? std::max(c->max_batch, fused_cap) : std::max(c->max_batch, HH_SEG_BATCH);
+                   : c->n_segments == 1 ? std::max(c->max_batch, fused_cap) : std::max(c->max_batch, seg_batch(c->n));
   const int64_t per_batch = plan.len <= bmax ? bmax / plan.len : 1;
   const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
   int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
@@ -3494,7 +3503,7 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   const int s_pad = multi ? (n_segments + 63) / 64 * 64 : 0;
   // several segments: the shared-twist pipelines batch up to HH_SEG_BATCH candidates (q of a batch lives in HBM:
   // 0.5 MB per candidate at N = 512), the general pipeline max_batch
-  const int b_pad = multi ? (std::max(c->max_batch, HH_SEG_BATCH) + 63) / 64 * 64 : 0;
+  const int b_pad = multi ? (std::max(c->max_batch, seg_batch(c->n)) + 63) / 64 * 64 : 0;
   std::vector<float2> w2(nh);
   std::vector<float> wecm(multi ? (size_t)s_pad * nh : 0, 0.f);
   c->ref.assign(n_segments, RefConsts{});
