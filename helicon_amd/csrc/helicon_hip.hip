@@ -3880,6 +3880,66 @@ int hh_cross_correlation_f64(hh_ctx* c, const double* a, const double* b, int64_
 int hh_cosine_similarity(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
 int hh_cosine_similarity_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
 
+}  // extern "C"
+
+namespace {
+// scipy.ndimage.affine_transform(data, matrix, offset, order = 1, mode = "constant", cval = 0) of a 2-D image — what
+// helicon.rotate_shift_image (lib/transforms.py:315-369) calls: output pixel (y, x) samples the input at
+// c = M (y, x) + offset in float64; a coordinate outside [0, n - 1] on either axis gives 0 (ni_interpolation.c maps it
+// to -1 and takes the constant); inside, the two-point linear weights on floor(c), floor(c) + 1 (an index past the
+// edge only ever carries weight 0).
+__global__ __launch_bounds__(256) void k_affine_bilinear(const float* __restrict__ in, int ny, int nx, double m00, double m01,
+                                                         double m10, double m11, double o0, double o1, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= nx) return;
+  const double cy = m00 * (double)y + m01 * (double)x + o0;
+  const double cx = m10 * (double)y + m11 * (double)x + o1;
+  float v = 0.f;
+  if (cy >= 0.0 && cy <= (double)(ny - 1) && cx >= 0.0 && cx <= (double)(nx - 1)) {
+    const double fy = floor(cy), fx = floor(cx);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const double wy = cy - fy, wx = cx - fx;
+    const int y1 = min(y0 + 1, ny - 1), x1 = min(x0 + 1, nx - 1);
+    // scipy sums over the 2 x 2 support in (y, x) order with weights w_y w_x
+    double acc = 0.0;
+    acc += (double)in[(size_t)y0 * nx + x0] * ((1.0 - wy) * (1.0 - wx));
+    acc += (double)in[(size_t)y0 * nx + x1] * ((1.0 - wy) * wx);
+    acc += (double)in[(size_t)y1 * nx + x0] * (wy * (1.0 - wx));
+    acc += (double)in[(size_t)y1 * nx + x1] * (wy * wx);
+    v = (float)acc;
+  }
+  out[(size_t)y * nx + x] = v;
+}
+}  // namespace
+
+extern "C" {
+
+int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const double matrix[4], const double offset[2],
+                           float* out) {
+  if (!data || !out || !matrix || !offset || ny < 1 || nx < 1)
+    return fail(nullptr, HH_ERR_ARG, "hh_affine_transform_2d: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, HH_ERR_HIP, "hh_affine_transform_2d: no such HIP device (there is no CPU fallback)");
+  const size_t bytes = (size_t)ny * nx * sizeof(float);
+  float *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&d_in, bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_out, bytes);
+  if (e == hipSuccess) e = hipMemcpy(d_in, data, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_affine_bilinear, dim3((nx + 255) / 256, ny), dim3(256), 0, 0, d_in, ny, nx, matrix[0], matrix[1],
+                       matrix[2], matrix[3], offset[0], offset[1], d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_affine_transform_2d: ") + hipGetErrorString(e));
+  return HH_OK;
+}
+
 int hh_apply_helical_symmetry(int device, const float* data, const int32_t in_shape[3], double apix,
                               double twist_degree, double rise_angstrom, int csym, double fraction,
                               const int32_t new_size[3], double new_apix, float* out, int32_t out_shape[3],

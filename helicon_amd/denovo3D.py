@@ -36,6 +36,8 @@ __all__ = [
     "low_high_pass_filter",
     "threshold_data",
     "apply_helical_symmetry",
+    "rotate_shift_image",
+    "is_vertical",
     "units_to_cylindrical",
 ]
 
@@ -486,6 +488,39 @@ def threshold_data(data, thresh_fraction=None, thresh_value=None, *, device=0):
     return eng.threshold_data(d, thresh_fraction, thresh_value).astype(d.dtype if d.dtype.kind == "f" else np.float64)
 
 
+def rotate_shift_image(data, angle=0, pre_shift=(0, 0), post_shift=(0, 0), rotation_center=None, order=1, *, device=0):
+    """``helicon.rotate_shift_image`` (lib/transforms.py:315-369): rotate by ``angle`` degrees about ``rotation_center``
+    (default: the pixel (ny // 2, nx // 2)) with (y, x) shifts before and after, resampled as
+    ``scipy.ndimage.affine_transform(order=1, mode="constant")`` does — on the device (``hh_affine_transform_2d``).
+    The 2 x 2 matrix and the offset are float32 quantities in the reference; they are formed the same way here."""
+    d = np.asarray(data)
+    if d.ndim != 2:
+        raise ValueError("data must be a 2D image")
+    if order != 1:
+        raise NotImplementedError("the device resampler provides order=1 (the reference's default)")
+    if angle == 0 and pre_shift == [0, 0] and post_shift == [0, 0]:   # (the reference's test: lists only)
+        return d * 1.0
+    ny, nx = d.shape
+    centre = np.array((ny // 2, nx // 2), dtype=np.float32) if rotation_center is None else np.array(rotation_center, dtype=np.float32)
+    a = np.deg2rad(angle)
+    m = np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]], dtype=np.float32)
+    offset = -np.dot(m, np.array(post_shift, dtype=np.float32))   # the shift after the rotation
+    offset += centre - np.dot(m, centre)                          # rotation about the centre
+    offset += -np.array(pre_shift, dtype=np.float32)              # the shift before it
+    img = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.empty_like(img)
+    mat = (C.c_double * 4)(*[float(v) for v in m.ravel()])
+    off = (C.c_double * 2)(*[float(v) for v in offset])
+    _lib.check(_lib.lib().hh_affine_transform_2d(int(device), _ptr(img, C.c_float), ny, nx, mat, off, _ptr(out, C.c_float)), None)
+    return out if d.dtype == np.float32 else out.astype(d.dtype if d.dtype.kind == "f" else np.float64)
+
+
+def is_vertical(data):
+    """webApps/denovo3D/utils.py:429-447: the strongest column sum exceeds the strongest row sum."""
+    d = np.asarray(data)
+    return bool(np.max(np.sum(d, axis=0)) > np.max(np.sum(d, axis=1)))
+
+
 def apply_helical_symmetry(data, apix, twist_degree, rise_angstrom, csym=1, fraction=1.0, new_size=None,
                            new_apix=None, cpu=1, *, device=0, return_kernel_ms=False):
     """transforms.py:58-74 (same positional signature; ``cpu`` is accepted and ignored).  ``new_size=None``
@@ -593,7 +628,7 @@ def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_d
     if low_pass is not None and low_pass > 2 * apix:
         data = low_high_pass_filter(data, low_pass_fraction=2 * apix / low_pass,
                                     high_pass_fraction=2.0 / np.max(data.shape), device=device)
-    if transpose is not None and transpose > 0:  # transpose < 0 = "if vertical" needs is_vertical (skimage)
+    if transpose is not None and (transpose > 0 or (transpose < 0 and is_vertical(data))):   # pipeline.py:202-203
         data = data.T
     ny, nx = data.shape
     if thresh_fraction is not None and thresh_fraction >= 0:
@@ -642,8 +677,6 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
         return None
     if denoise or horizontalize:
         raise NotImplementedError("denoise / horizontalize need scikit-image and are outside the accelerated path")
-    if transpose is not None and transpose < 0:
-        raise NotImplementedError("transpose < 0 (transpose if vertical) needs is_vertical and is outside the accelerated path")
     if tube_diameter is not None and tube_diameter < 0:
         raise NotImplementedError("auto tube diameter (estimate_helix_rotation_center_diameter) needs scikit-image")
     apix = float(apix2d_orig)
@@ -655,7 +688,7 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
     device = int(opts.get("device", 0))
     mask = opts.get("mask")
     log = bool(opts.get("log", True))
-    pkey = (dkey, apix, None if low_pass is None else float(low_pass), None if transpose is None else int(transpose > 0),
+    pkey = (dkey, apix, None if low_pass is None else float(low_pass), None if transpose is None else int(np.sign(transpose)),
             None if thresh_fraction is None else float(thresh_fraction), float(tube_diameter), device)
     with _prepared_lock:
         prepared = _prepared.get(pkey)

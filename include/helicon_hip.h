@@ -12,6 +12,7 @@
  *   hh_cross_correlation   lib/analysis.py:777-799            cross_correlation_coefficient
  *   hh_cosine_similarity   lib/analysis.py:802-821            cosine_similarity
  *   hh_apply_helical_symmetry  lib/transforms.py:58-165       apply_helical_symmetry
+ *   hh_affine_transform_2d lib/transforms.py:315-369          rotate_shift_image (its scipy.ndimage.affine_transform call)
  *   hh_set_reference +     webApps/denovo3D/app.py:2455-2523  reconstruction_task (the pool over
  *   hh_sweep[_device]                                         candidates) scoring each candidate by
  *                                                             cc(ref[mask], pwr[mask])
@@ -196,6 +197,15 @@ int hh_cross_correlation(hh_ctx* ctx, const float* a, const float* b, int64_t n,
 int hh_cosine_similarity(hh_ctx* ctx, const float* a, const float* b, int64_t n, double* out);
 int hh_cross_correlation_f64(hh_ctx* ctx, const double* a, const double* b, int64_t n, double* out);
 int hh_cosine_similarity_f64(hh_ctx* ctx, const double* a, const double* b, int64_t n, double* out);
+
+/* The resampling step of helicon.rotate_shift_image (lib/transforms.py:315-369; used by the app's
+ * auto_horizontalize, webApps/denovo3D/utils.py:410, 423): scipy.ndimage.affine_transform(data, matrix, offset,
+ * order = 1, mode = "constant") of one ny x nx float32 image — out[y][x] = bilinear sample of data at
+ * matrix (y, x) + offset (row-major 2 x 2 matrix, (y, x) offset), 0 where the sample point leaves [0, n - 1].
+ * The caller builds matrix / offset from the angle, shifts and rotation centre exactly as the reference does
+ * (helicon_amd.rotate_shift_image shows it).  Context-free: errors are read with hh_last_error(NULL). */
+int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const double matrix[4], const double offset[2],
+                           float* out);
 
 /* Helical symmetrisation of a 3-D map (transforms.py:58-165): data is host float32
  * [in_shape[0]][in_shape[1]][in_shape[2]] (z, y, x); new_size / new_apix as in the reference (pass the

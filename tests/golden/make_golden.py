@@ -372,17 +372,48 @@ def g7_helical_sym():
     np.savez_compressed(OUT / "g7_helical_sym.npz", **arrs)
 
 
+def g8_rotate_shift():
+    """helicon.rotate_shift_image (lib/transforms.py:315-369: scipy affine_transform, order 1, constant) and the app's
+    is_vertical (webApps/denovo3D/utils.py:429-447)."""
+    rng = np.random.default_rng(8)
+    out = {}
+    cases = [
+        # (ny, nx, angle, pre_shift, post_shift, rotation_center)
+        (32, 48, 7.5, (0, 0), (0, 0), None),
+        (48, 32, -33.0, (1.5, -2.0), (0.25, 3.0), None),
+        (40, 40, 90.0, (0, 0), (2, -1), None),
+        (31, 45, 12.25, (0.5, 0.5), (0, 0), (10.0, 20.5)),
+        (64, 64, 0.0, (3, 0), (0, -4), None),
+        (25, 25, 180.0, (0, 0), (0, 0), None),
+    ]
+    for k, (ny, nx, ang, pre, post, rc) in enumerate(cases):
+        img = rng.normal(size=(ny, nx)).astype(np.float32)
+        got = transforms.rotate_shift_image(img, angle=ang, pre_shift=pre, post_shift=post,
+                                            rotation_center=None if rc is None else np.array(rc))
+        out[f"case{k}_image"] = img
+        out[f"case{k}_args"] = np.array([ang, *pre, *post, *(rc if rc is not None else (np.nan, np.nan))], dtype=np.float64)
+        out[f"case{k}_out"] = np.asarray(got)
+    # is_vertical: a horizontal and a vertical bar, and noise images
+    for k in range(6):
+        img = rng.normal(size=(24, 36)).astype(np.float32)
+        if k == 0:
+            img[10:14, :] += 5
+        if k == 1:
+            img[:, 16:20] += 5
+        out[f"vert{k}_image"] = img
+        out[f"vert{k}"] = np.array([bool(utils.is_vertical(img))])
+    np.savez_compressed(OUT / "g8_rotate_shift.npz", **out)
+    print("g8_rotate_shift", len(cases))
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
-    g1_simulate()
-    g2_scores()
-    g3_composed()
-    g3b_general_sizes()
-    g4_path_a()
-    g4b_path_a_linear()
-    g5_lsq()
-    g6_filters()
-    g7_helical_sym()
+    makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
+              g7_helical_sym, g8_rotate_shift]
+    only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
+    for make in makers:
+        if not only or make.__name__ in only:
+            make()
     (OUT / "VERSIONS.json").write_text(json.dumps(versions(), indent=1) + "\n")
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -156,12 +156,12 @@ def test_device_argmax_matches_numpy_rule():
 
 # ---------------------------------------------------------------------------- the task function under a pool
 def _task_args(data, twist, rise, *, n=None, image_file=None, image_index=0, algorithm=None, target_apix2d=5.0,
-               low_pass=0, thresh_fraction=-1):
+               low_pass=0, thresh_fraction=-1, transpose=0):
     """The 36-tuple of app.py:2407-2446 (apix 5 A/pixel, the app's default target_apix2d = target_apix3d = 5)."""
     n = data.shape[0] if n is None else n
     apix = 5.0
     return (0, 1, data, image_file, image_index, twist, rise, (rise, rise), 1, 0.0, (0, 0), 0.0, (0, 0), 0.0, (0, 0),
-            apix, "", low_pass, 0, 0, 5.0, target_apix2d, thresh_fraction, -1, n * apix, 0.4 * n * apix, 0,
+            apix, "", low_pass, transpose, 0, 5.0, target_apix2d, thresh_fraction, -1, n * apix, 0.4 * n * apix, 0,
             -1, -1, "linear", 0, 0, "cosine", algorithm or {}, 0, 1)
 
 
@@ -263,3 +263,42 @@ def test_c_abi_allgather_single_rank_rccl():
     np.testing.assert_array_equal(got[:, :g], ref)
     assert np.isnan(got[:, g:]).all()
     assert best.tolist() == np.argmax(ref, axis=1).tolist()
+
+
+# ---------------------------------------------------------------------------- image preparation: rotate / shift, transpose
+def test_rotate_shift_image_reproduces_the_reference(golden_dir):
+    """helicon.rotate_shift_image (lib/transforms.py:315-369; scipy affine_transform order 1, constant) on the device
+    against the reference's outputs (fixture G8): the same pixels fall outside the input, values within 1e-6."""
+    g = np.load(golden_dir / "g8_rotate_shift.npz")
+    for k in range(6):
+        a = g[f"case{k}_args"]
+        rc = None if np.isnan(a[5]) else np.array((a[5], a[6]))
+        got = H.rotate_shift_image(g[f"case{k}_image"], a[0], (a[1], a[2]), (a[3], a[4]), rc)
+        want = g[f"case{k}_out"]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        np.testing.assert_array_equal(got == 0, want == 0)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    big = np.random.default_rng(3).normal(size=(700, 900)).astype(np.float32)
+    np.testing.assert_allclose(H.rotate_shift_image(big, 17.0, (2.5, -1.0), (0.0, 4.0)),
+                               O.rotate_shift_image(big, 17.0, (2.5, -1.0), (0.0, 4.0)), rtol=0, atol=2e-6)
+    assert H.rotate_shift_image(big, 0, [0, 0], [0, 0]) is not big      # the reference's early return: a copy (data * 1.0)
+    with pytest.raises(NotImplementedError):
+        H.rotate_shift_image(big, 5.0, order=3)
+    for k in range(6):
+        assert H.is_vertical(g[f"vert{k}_image"]) == bool(g[f"vert{k}"][0])
+
+
+def test_process_one_task_transposes_a_vertical_image():
+    """pipeline.py:202-203: transpose < 0 transposes when utils.is_vertical says so — a vertical helix scores like its
+    transposed (horizontal) self, and a horizontal one is left alone."""
+    n, apix = 128, 5.0
+    d, br = 0.4 * n * apix, 2 * apix
+    img = O.simulate_helical_projection(1, 29.0, 25.0, 1, d, br, 0, 0, n, n, apix).astype(np.float32)
+    algo = dict(helical_diameter=d, ball_radius=br)
+    assert not H.is_vertical(img) and H.is_vertical(img.T)
+    s_h = H.process_one_task(*_task_args(img, 29.0, 25.0, algorithm=algo))[0]
+    s_auto = H.process_one_task(*_task_args(np.ascontiguousarray(img.T), 29.0, 25.0, algorithm=algo, transpose=-1))[0]
+    s_same = H.process_one_task(*_task_args(img, 29.0, 25.0, algorithm=algo, transpose=-1))[0]
+    s_forced = H.process_one_task(*_task_args(np.ascontiguousarray(img.T), 29.0, 25.0, algorithm=algo, transpose=1))[0]
+    assert s_auto == pytest.approx(s_h, abs=1e-6) and s_same == pytest.approx(s_h, abs=1e-6) and s_forced == pytest.approx(s_h, abs=1e-6)
+    assert s_h > 0.9
