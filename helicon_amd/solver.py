@@ -55,8 +55,9 @@ def get_cylindrical_mask(nz, ny, nx, rmin=0, rmax=-1, return_xyz=False):
 
 def cosine_similarity(a, b):
     """lib/analysis.py:802-821 on host vectors (the prediction A_data x comes back from the device)."""
-    norm = np.linalg.norm(a) * np.linalg.norm(b)
-    return 0 if norm == 0 else np.sum(a * b) / norm
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    norm = np.sqrt(_dot(a, a)) * np.sqrt(_dot(b, b))
+    return 0 if norm == 0 else _dot(a, b) / norm
 
 
 class PathAProblem:
@@ -143,6 +144,14 @@ class PathAProblem:
 
 
 # ---- scipy.optimize.lsq_linear(method="trf", lsq_solver="lsmr", lsmr_tol="auto") around the device operator ----------
+def _dot(a, b):
+    """Inner product as an index-ordered pairwise sum (``np.add.reduce``), not BLAS: one thread, one summation order.
+    ``np.dot`` hands these 50k-element vectors to OpenBLAS, whose worker threads (one per host core: 256 on the GPU
+    box, under a 16-core quota) made a 0.1 s solve take 0.4 - 0.7 s, and whose blocking makes the rounding depend on
+    the thread count — which the loosely converged trust-region iteration amplifies to 1e-3 in the score."""
+    return float(np.add.reduce(a * b))
+
+
 def _in_bounds(x, lb, ub):
     return np.all((x >= lb) & (x <= ub))
 
@@ -194,19 +203,19 @@ def _step_to_bound(x, s, lb, ub):
 
 def _quad_1d(jdot, g, s, diag=None, s0=None):
     v = jdot(s)
-    a = np.dot(v, v)
+    a = _dot(v, v)
     if diag is not None:
-        a += np.dot(s * diag, s)
+        a += _dot(s * diag, s)
     a *= 0.5
-    b = np.dot(g, s)
+    b = _dot(g, s)
     if s0 is None:
         return a, b
     u = jdot(s0)
-    b += np.dot(u, v)
-    c = 0.5 * np.dot(u, u) + np.dot(g, s0)
+    b += _dot(u, v)
+    c = 0.5 * _dot(u, u) + _dot(g, s0)
     if diag is not None:
-        b += np.dot(s0 * diag, s)
-        c += 0.5 * np.dot(s0 * diag, s0)
+        b += _dot(s0 * diag, s)
+        c += 0.5 * _dot(s0 * diag, s0)
     return a, b, c
 
 
@@ -224,10 +233,10 @@ def _min_quad_1d(a, b, lb, ub, c=0):
 
 def _eval_quad(jdot, g, s, diag=None):
     js = jdot(s)
-    q = np.dot(js, js)
+    q = _dot(js, js)
     if diag is not None:
-        q += np.dot(s * diag, s)
-    return 0.5 * q + np.dot(s, g)
+        q += _dot(s * diag, s)
+    return 0.5 * q + _dot(s, g)
 
 
 def _solve_bounded(P: PathAProblem, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxiter=1000):
@@ -244,7 +253,7 @@ def _solve_bounded(P: PathAProblem, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxi
     x = _strictly_feasible(_reflect(x_lsq, lb, ub), lb, ub, rstep=0.1)
     r = P.matvec(x) - b
     g = P.rmatvec(r)
-    cost = 0.5 * np.dot(r, r)
+    cost = 0.5 * _dot(r, r)
     status, it = None, -1
     adot = P.matvec
     for it in range(max_iter):
@@ -268,7 +277,7 @@ def _solve_bounded(P: PathAProblem, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxi
         ltol = max(EPS, min(0.1, eta * g_norm))
         p_h = -P.lsmr(np.concatenate((r, np.zeros(n))), d=d, root=root, atol=ltol, btol=ltol, maxiter=lsmr_maxiter)[0]
         p = d * p_h
-        p_dot_g = np.dot(p, g)
+        p_dot_g = _dot(p, g)
         if p_dot_g > 0:
             status = -1
         theta = 1 - min(0.005, g_norm)
@@ -327,7 +336,7 @@ def _solve_bounded(P: PathAProblem, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxi
         g = P.rmatvec(r)
         if cost_change < tol * cost:
             status = 2
-        cost = 0.5 * np.dot(r, r)
+        cost = 0.5 * _dot(r, r)
         if status is not None:
             break
     return x, (0 if status is None else status), it + 1

@@ -147,8 +147,9 @@ def test_lsq_reconstruct_trilinear(golden_dir):
     converged (lsq_linear tol = 1e-2), and on the seed-42 noise image (158 equations, 200 unknowns) the trust-region
     loop's stopping test is borderline: perturbing the oracle's own matrix entries by 1e-8 relative moves its score
     between 0.9709, 0.9720 and 0.9729 (termination status 1 or 2, 9 or 10 iterations).  The reference itself runs its
-    first LSMR in float32.  Hence 2e-3 on scores and volumes compared by their cosine.  What the device does guarantee
-    is repeatability: A^T y accumulates in 64-bit fixed point (integer atomics), so two runs agree bit for bit."""
+    first LSMR in float32.  Hence 2e-3 on scores and volumes compared by their cosine.  What the product does guarantee
+    is repeatability: A^T y accumulates in 64-bit fixed point (integer atomics) and the host glue's inner products are
+    index-ordered pairwise sums (no BLAS threads), so two runs — and two processes — agree bit for bit."""
     g = np.load(golden_dir / "g4b_path_a_linear.npz")
     kw = dict(reconstruct_diameter_2d_pixel=8, reconstruct_diameter_3d_pixel=8, reconstruct_length_2d_pixel=8,
               reconstruct_length_3d_pixel=8, sym_oversample=1, interpolation="linear")
