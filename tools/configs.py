@@ -36,7 +36,7 @@ def run(name, eng, grid, reps=2):
 
 
 tw, rs = H.sweep_axis(0.01, 4.00, 0.01), H.sweep_axis(4.000, 5.245, 0.005)
-which = sys.argv[1:] or ["C3", "C4", "C5", "LOWRES", "GEN", "SHARDS"]
+which = sys.argv[1:] or ["C3", "C4", "C5", "LOWRES", "GEN", "SMALL", "SHARDS"]
 if "C3" in which:
     run("C3 512^2, 400x250 grid x Csym 1..6", make(512, 1), H.build_grid(tw, rs, (1, 2, 3, 4, 5, 6), tube_length=512.0), reps=1)
 if "C4" in which:
@@ -52,6 +52,9 @@ if "GEN" in which:  # sizes that are not powers of two: the runtime-sized kernel
     for shape, nt in (((200, 200), 200), ((400, 400), 100), ((300, 480), 100)):
         run(f"general {shape[0]}x{shape[1]}, {nt}x250 grid", make(shape, 1),
             H.build_grid(tw[:nt], rs, (1,), tube_length=float(shape[1])), reps=1)
+if "SMALL" in which:  # the smaller power-of-two sides through the tuned kernels (configs[0] is a 256 x 256 image)
+    for n in (256, 128):
+        run(f"{n}^2, 400x250 grid", make(n, 1), H.build_grid(tw, rs, (1,), tube_length=float(n)), reps=3)
 if "SHARDS" in which:  # what one rank of a strong-scaling run sweeps: whole twists of the C2 grid, 1/N of them
     eng = make(512, 1)
     for ranks in (1, 2, 4, 8):
