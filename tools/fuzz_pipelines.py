@@ -35,9 +35,11 @@ for case in range(cases):
     else:
         rise0 = float(rng.choice([rng.uniform(1.0, 30.0) * apix, rng.uniform(0.3, 1.0) * apix, n * apix * 0.3]))
     rise0 = min(rise0, 0.45 * n * apix)
-    n_rises = int(rng.choice([8, 9, 16, 33, 70]))
+    n_rises = int(rng.choice([8, 9, 16, 33, 70, 250, 701], p=[0.2, 0.15, 0.2, 0.15, 0.15, 0.1, 0.05]))
     rises = rise0 * (1.0 + float(rng.choice([1e-4, 3e-3, 0.02])) * np.arange(n_rises))
-    twists = np.round(rng.uniform(-170, 170, int(rng.integers(1, 5))), 3)
+    # (now and then many runs: the launch then spans several rounds of resident workgroups and the schedule cuts the
+    # last runs finer than the first ones)
+    twists = np.round(rng.uniform(-170, 170, int(rng.integers(1, 5)) if case % 7 else int(rng.integers(20, 120))), 3)
     units = None
     if case % 4 == 0:
         k = int(rng.integers(2, 4))

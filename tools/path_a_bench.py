@@ -41,6 +41,17 @@ def main():
         print(f"{interp}: unknowns {dims[0]}, data rows {dims[1]}, symmetry rows {dims[2]}, operations {dims[3]}; set-up "
               f"{t_setup * 1e3:.1f} ms, A x + A^T y (host vectors) {t_pair * 1e3:.2f} ms, lsq_reconstruct {t_call * 1e3:.1f} ms; "
               f"scores at 27/29/31 deg {np.round(scores, 4)}", flush=True)
+    # the reference drives its scorer from a thread pool (app.py:2473-2476): calls on different candidates overlap on the
+    # device (one hh_pa and one stream each; ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    twists = [27.0 + 0.25 * k for k in range(32)]
+    for threads in (1, 4, 8, 16):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            scores = list(pool.map(lambda tw: lsq_reconstruct(image, 1.0, tw, 4.0, 1, interpolation="nn", **kw)[1], twists))
+        dt = time.perf_counter() - t0
+        print(f"nn, {len(twists)} candidates from {threads} thread(s): {len(twists) / dt:.1f} candidates/s; best twist "
+              f"{twists[int(np.argmax(scores))]}", flush=True)
     if "--oracle" in sys.argv:
         from oracle import path_a as A
         t0 = time.perf_counter()
