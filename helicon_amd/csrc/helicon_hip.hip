@@ -2920,8 +2920,10 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   // The fused pass has no intermediate to hold, so its batches are not tied to max_batch: long
   // launches even out the tail of the grid (C2: 3.2 M candidates/s at 250 per launch, 3.8 M at 4000).
   const int fused_cap = (int)std::max<int64_t>(1024, std::min<int64_t>(HH_FUSED_BATCH, HH_FUSED_BYTES / ((int64_t)2 * std::max(1, plan.kg) * c->n * 4)));
+  // (never more than the sweep itself holds: the factor and moment buffers are sized by it and only grow)
   const int bmax = !plan.fused ? c->max_batch
-                   : c->n_segments == 1 ? std::max(c->max_batch, fused_cap) : std::max(c->max_batch, seg_batch(c->n));
+                   : (int)std::min<int64_t>(c->n_segments == 1 ? std::max(c->max_batch, fused_cap) : std::max(c->max_batch, seg_batch(c->n)),
+                                            std::max<int64_t>(count_cand, 16));
   const int64_t per_batch = plan.len <= bmax ? bmax / plan.len : 1;
   const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
   int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
