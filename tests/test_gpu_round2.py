@@ -302,3 +302,29 @@ def test_process_one_task_transposes_a_vertical_image():
     s_forced = H.process_one_task(*_task_args(np.ascontiguousarray(img.T), 29.0, 25.0, algorithm=algo, transpose=1))[0]
     assert s_auto == pytest.approx(s_h, abs=1e-6) and s_same == pytest.approx(s_h, abs=1e-6) and s_forced == pytest.approx(s_h, abs=1e-6)
     assert s_h > 0.9
+
+
+# ---------------------------------------------------------------------------- launch schedule of the fused pass
+@pytest.mark.parametrize("n,n_twists,n_rises", [(128, 37, 93), (64, 300, 40), (256, 9, 701), (512, 50, 250), (128, 1, 3000)])
+def test_fused_launch_schedules_agree_with_the_transform_pipeline(n, n_twists, n_rises):
+    """The fused pass cuts a launch's runs into workgroups by the device's resident-workgroup count (long workgroups for
+    whole rounds, finer pieces for the last round; one rank's share of a strong-scaling run is the (512, 50, 250) shape):
+    whatever the cut, every candidate is scored once and like the general pipeline scores it."""
+    apix = 2.0
+    eng = H.SweepEngine(n)
+    eng.set_geometry(apix=apix, helical_diameter=0.45 * n * apix, ball_radius=2.5 * apix)
+    rng = np.random.default_rng(n + n_twists)
+    twists = np.round(np.sort(rng.uniform(-60, 60, n_twists)), 3)
+    rises = 6.0 * apix * (1.0 + 2e-4 * np.arange(n_rises))
+    img = eng.simulate(float(twists[n_twists // 2]), float(rises[n_rises // 2]), 1)
+    eng.set_reference((img + rng.normal(0, 0.3 * img.std(), img.shape)).astype(np.float32)[None], H.radial_band_mask(n, n))
+    params = np.array([[tw, rs, 1, 0.0] for tw in twists for rs in rises])
+    eng.set_table_path(2)
+    got = eng.sweep(params)
+    assert eng.last_first_pass == "fused"
+    eng.set_table_path(0)
+    step = max(1, len(params) // 4000)          # the general pipeline on a strided sample (and on the grid's two ends)
+    pick = np.unique(np.r_[0:min(300, len(params)), np.arange(0, len(params), step), len(params) - min(300, len(params)):len(params)])
+    want = eng.sweep(params[pick])
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[:, pick], want, rtol=0, atol=5e-5)
