@@ -3825,9 +3825,8 @@ int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_ou
 int hh_low_high_pass_filter(hh_ctx* c, const float* image, double low_pass_fraction, double high_pass_fraction,
                             float* out) {
   if (!c || !image || !out) return fail(c, HH_ERR_ARG, "hh_low_high_pass_filter: bad argument");
-  if (c->general)
-    return fail(c, HH_ERR_ARG, "hh_low_high_pass_filter: the device filter serves square power-of-two images only");
   HH_HIP(c, hipSetDevice(c->device));
+  if (c->general) return gen_low_high_pass_filter(c, image, low_pass_fraction, high_pass_fraction, out);
   const int n = c->n;
   const size_t npix = (size_t)n * n, nh = (size_t)(n / 2 + 1) * n;
   int rc = ensure_img(c, 2);  // [0] input, [1] output

@@ -312,8 +312,6 @@ class SweepEngine:
 
     def low_high_pass_filter(self, image, low_pass_fraction=0.0, high_pass_fraction=0.0) -> np.ndarray:
         img = _f32(image)
-        if self.general:
-            raise NotImplementedError("the device low/high-pass filter serves square power-of-two images")
         if img.shape != (self.ny, self.nx):
             raise ValueError(f"image must be [{self.ny}, {self.nx}]")
         out = np.empty_like(img)
@@ -466,16 +464,15 @@ def cosine_similarity(a, b, *, device=0):
 
 
 def low_high_pass_filter(data, low_pass_fraction=0, high_pass_fraction=0, *, device=0):
-    """``helicon.low_high_pass_filter`` (lib/filters.py:314-372) for a square power-of-two 2-D image:
-    Gaussian low / high pass in Fourier space on the device, float32 arithmetic, float64 result like
-    the reference's.  3-D input is outside the accelerated path."""
+    """``helicon.low_high_pass_filter`` (lib/filters.py:314-372) for a 2-D image of any size: Gaussian low / high
+    pass in Fourier space on the device (square power-of-two sides: the sweep's own float32 transforms; anything else:
+    direct float64 transforms), float64 result like the reference's.  3-D input is outside the accelerated path."""
     d = np.asarray(data)
     if d.ndim == 3:
         raise NotImplementedError("3-D low_high_pass_filter is outside the accelerated path")
     if d.ndim != 2:
         raise ValueError("Input data must be a 2D or 3D array.")  # filters.py:336-337
-    side = _square_side(*d.shape)
-    return _engine(side, device).low_high_pass_filter(d, low_pass_fraction, high_pass_fraction).astype(np.float64)
+    return _engine(_image_shape(*d.shape), device).low_high_pass_filter(d, low_pass_fraction, high_pass_fraction).astype(np.float64)
 
 
 def threshold_data(data, thresh_fraction=None, thresh_value=None, *, device=0):
@@ -641,6 +638,97 @@ def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_d
     return data
 
 
+def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
+              target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
+              reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device, transpose,
+              low_pass):
+    """pipeline.py:242-496 with target_apix2d = apix2d_orig (no rescale): the reconstruction box from the tube's
+    dimensions, ``lsq_reconstruct``, helical symmetrisation back on the input's grid, projections and z sections."""
+    from .solver import lsq_reconstruct
+
+    if tilt or psi or dy:
+        raise NotImplementedError("scorer 'lsq': tilt / psi / dy need the reference's cubic map_coordinates resampling of the map")
+    # the image the reference would have at pipeline.py:286 (``prepared`` already went through the low pass, the
+    # transpose and, with thresh_fraction >= 0, the background subtraction + threshold + / max), and its ``data_orig``
+    img = np.asarray(prepared)
+    ny, nx = img.shape
+    if thresh_fraction is not None and thresh_fraction >= 0:
+        # data_orig is the image after the in-place median subtraction (pipeline.py:277-282: ``data_orig = data`` aliases it)
+        base = _prepare_task_image(data, apix, low_pass, transpose, None, tube_diameter, device)
+        rec_d0 = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
+        nr = min(ny // 2 - 1, int(np.ceil(rec_d0 / 2 / apix) + 1))
+        data_orig = np.asarray(base) - np.median(np.asarray(base)[(ny // 2 - nr, ny // 2 + nr), :])
+        data_orig = data_orig.astype(np.asarray(base).dtype, copy=False)
+    else:
+        data_orig = img
+    a2 = apix
+    # tube length, reconstruction diameter / length (pipeline.py:242-266)
+    if tube_length < 0:
+        tube_length = int(nx * apix) if tube_diameter > ny * apix / 2 else round(np.sqrt((nx * apix) ** 2 / 4 - tube_diameter ** 2 / 4) * 2)
+    rec_d = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
+    rec_d_inner = tube_diameter_inner if 0 < tube_diameter_inner < rec_d else 0
+    if reconstruct_length < rise:
+        reconstruct_length = max(min(3 * np.max(rise_range), tube_length),
+                                 round(np.tan(np.deg2rad(np.max(np.abs(tilt_range)))) * tube_diameter * 3))
+    # voxel size (pipeline.py:288-300)
+    if target_apix3d < 0:
+        vol = reconstruct_length * (rec_d ** 2 - rec_d_inner ** 2) / 4 * np.pi
+        a3 = max(a2, round(np.power(vol / (nx * ny), 1 / 3) + 0.5))
+    elif target_apix3d == 0:
+        a3 = a2
+    else:
+        a3 = target_apix3d
+    # box sizes in pixels, all even (pipeline.py:305-331)
+    even = lambda v: v + v % 2  # noqa: E731
+    d3 = even(int(round(rec_d / a3)))
+    d3_inner = int(round(tube_diameter_inner / a3))
+    d2 = even(int(round(rec_d / a2)))
+    len2 = tube_length if 0 < tube_length < nx * a2 else nx * a2
+    l2 = even(int(len2 / a2))
+    if reconstruct_length > 0:
+        l3 = even(max(int(np.ceil(rise / a3)), int(np.ceil(reconstruct_length / a3))))
+    else:
+        l3 = even(int(l2 * a2 / a3 + 0.5))
+    if sym_oversample <= 0:  # pipeline.py:333-345
+        ratio = 2 ** 20 / (l3 * (d3 ** 2 - d3_inner ** 2))
+        if ratio < 10:
+            sym_oversample = max(1, int(round(ratio)))
+        elif ratio < 100:
+            sym_oversample = max(1, int(round(ratio / 10)) * 10)
+        else:
+            sym_oversample = max(1, int(round(ratio / 100)) * 100)
+        if return_3d:
+            sym_oversample *= 2
+    model = {k: v for k, v in opts.items() if k in ("model",)} or {"model": "lsq"}
+    (rec3d, set1, set2), score = lsq_reconstruct(
+        img, a2 / a3, twist, rise / a3, csym, tilt, psi, dy / a2, thresh_fraction=thresh_fraction,
+        positive_constraint=positive_constraint, reconstruct_diameter_3d_inner_pixel=d3_inner,
+        reconstruct_diameter_2d_pixel=d2, reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2,
+        reconstruct_length_3d_pixel=l3, sym_oversample=sym_oversample, interpolation=interpolation, fsc_test=fsc_test,
+        score_metric=score_metric, target_apix2d=a2, algorithm=model, device=device)
+    # the map on the input's grid, at least 1.2 pitches long (pipeline.py:398-417)
+    tw_eff = twist if abs(twist) < 90 else 180 - abs(twist)
+    pitch_pixel = int(360 / abs(tw_eff) * rise / apix + 0.5) if abs(tw_eff) > 1e-2 else int(np.ceil(2 * rise / apix))
+    new_length = max(nx, int(pitch_pixel * 1.2))
+    sym = apply_helical_symmetry(rec3d, a3, twist, rise, csym, new_size=(new_length, ny, ny), new_apix=apix, device=device)
+    x_proj = np.sum(sym, axis=2).T
+    y_proj = np.sum(sym, axis=1).T
+    y_max = y_proj.max()
+    if y_max > 0:
+        y_proj = y_proj * (x_proj.max() / y_max)
+    per_rise = max(1, int(np.ceil(rise / apix)))
+    z0 = sym.shape[0] // 2 - per_rise // 2
+    z_sections = np.sum(sym[z0:z0 + per_rise], axis=0)
+    lo, hi = z_sections.min(), z_sections.max()
+    if hi > lo:
+        z_sections = (z_sections - lo) * (x_proj.max() - x_proj.min()) / (hi - lo) + x_proj.min()
+    return (
+        score,
+        (x_proj, y_proj, z_sections, (rec3d, set1, set2) if return_3d else None, d2, d3, l2, l3),
+        (data_orig, imageFile, imageIndex, a3, a2, twist, rise, csym, tilt, psi, dy),
+    )
+
+
 def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range,
                      psi, psi_range, dy, dy_range, apix2d_orig, denoise, low_pass, transpose, horizontalize,
                      target_apix3d, target_apix2d, thresh_fraction, positive_constraint, tube_length,
@@ -655,6 +743,12 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
     (pipeline.py:212 reads ``imageIndex - 1``).  ``target_apix2d`` below the image's own pixel size means
     "no rescale" (pipeline.py:268-272, filters.py:393-409); a larger one needs scikit-image's ``rescale``
     and is rejected, like denoise / horizontalize / auto tube diameter.
+
+    ``algorithm["scorer"] = "lsq"`` runs the reference's OWN scorer instead (pipeline.py:286-496): the sparse
+    least-squares reconstruction on the device (``helicon_amd.lsq_reconstruct``, model "lsq", interpolation "nn" or
+    "linear"), its cosine score, the helically symmetrised map (``apply_helical_symmetry``) and its x / y projections
+    and central z sections — the reference's complete return tuple.  Tilt, psi and dy must be zero there (the
+    reference resamples the map with a cubic ``map_coordinates`` otherwise).
 
     The reference's pool calls this once per (twist, rise) pair with the same image (app.py:2473-2476): the
     prepared image is cached by content, and the engine keeps the reference spectrum it was last given, so
@@ -698,6 +792,11 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
             if len(_prepared) >= _PREPARED_MAX:
                 _prepared.pop(next(iter(_prepared)))
             _prepared[pkey] = prepared
+    if opts.get("scorer", "spectrum") == "lsq":
+        return _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
+                         target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
+                         reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device,
+                         transpose, low_pass)
     ny, nx = _image_shape(*prepared.shape)
     diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))
     ball_radius = float(opts.get("ball_radius", 2.0 * apix))

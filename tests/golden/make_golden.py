@@ -406,10 +406,46 @@ def g8_rotate_shift():
     print("g8_rotate_shift", len(cases))
 
 
+def g9_process_one_task():
+    """The reference's own task function (webApps/denovo3D/pipeline.py:84-496) on a small helix, in the configuration the
+    GPU build reproduces end to end: no rescale (target_apix2d = apix2d_orig), no tilt / psi / dy, model "lsq"."""
+    from helicon.webApps.denovo3D import pipeline
+
+    ny, nx, apix = 32, 48, 5.0
+    img = utils.simulate_helical_projection(n=1, twist=29.0, rise=10.0, csym=1, helical_diameter=60.0, ball_radius=10.0,
+                                            polymer=0, planarity=0, ny=ny, nx=nx, apix=apix)
+    img = np.asarray(img, dtype=np.float32)
+    img = img + np.random.default_rng(9).normal(0, 0.05 * img.std(), img.shape).astype(np.float32)
+    out = {"image": img}
+    cases = [
+        # (twist, rise, csym, interpolation, thresh_fraction, target_apix3d, tube_diameter, low_pass)
+        (29.0, 10.0, 1, "nn", -1, 5.0, 100.0, 0),
+        (31.0, 10.0, 1, "nn", -1, 5.0, 100.0, 0),
+        (29.0, 10.0, 1, "linear", -1, 0, 100.0, 0),
+        (29.0, 10.0, 2, "nn", 0.05, 5.0, 120.0, 25.0),
+    ]
+    for k, (tw, rs, cs, interp, thr, a3, td, lp) in enumerate(cases):
+        res = pipeline.process_one_task(0, 1, img.copy(), "mem", 1, tw, rs, (rs, rs), cs, 0.0, (0, 0), 0.0, 0, 0.0, 0,
+                                        apix, "", lp, 0, 0, a3, apix, thr, -1, -1, td, 0, -1, 1, interp, 0, 1, "cosine",
+                                        {"model": "lsq"}, 0, 1)
+        score, ret, meta = res
+        out[f"case{k}_args"] = np.array([tw, rs, cs, {"nn": 0, "linear": 1}[interp], thr, a3, td, lp], dtype=np.float64)
+        out[f"case{k}_score"] = np.array([score], dtype=np.float64)
+        out[f"case{k}_x_proj"] = np.asarray(ret[0])
+        out[f"case{k}_y_proj"] = np.asarray(ret[1])
+        out[f"case{k}_z_sections"] = np.asarray(ret[2])
+        out[f"case{k}_rec3d"] = np.asarray(ret[3][0])
+        out[f"case{k}_dims"] = np.array(ret[4:8], dtype=np.int64)
+        out[f"case{k}_data_orig"] = np.asarray(meta[0])
+        out[f"case{k}_meta"] = np.array([meta[3], meta[4], meta[5], meta[6], meta[7], meta[8], meta[9], meta[10]], dtype=np.float64)
+        print("g9 case", k, score, ret[4:8], np.asarray(ret[0]).shape, np.asarray(ret[3][0]).shape)
+    np.savez_compressed(OUT / "g9_process_one_task.npz", **out)
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift]
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:
         if not only or make.__name__ in only:

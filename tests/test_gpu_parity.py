@@ -672,8 +672,15 @@ def test_low_high_pass_filter_and_threshold_match_golden_and_oracle(golden_dir):
         img = rng.normal(size=(n, n)).astype(np.float32) + 3.0
         ref = O.low_high_pass_filter(img.astype(np.float64), 0.25, 2.0 / n)
         np.testing.assert_allclose(H.low_high_pass_filter(img, 0.25, 2.0 / n), ref, rtol=0, atol=1e-5 * np.abs(img).max())
+    # any other size: direct float64 transforms on the device, the reference's fftshift placement of the filter included
+    # (for an odd side it is not the frequency's own position)
+    for shape in ((48, 48), (32, 48), (45, 63), (50, 70), (200, 300)):
+        img = rng.normal(size=shape).astype(np.float32) + 1.0
+        for lp, hp in ((0.25, 2.0 / max(shape)), (0.4, 0.0), (0.0, 0.1)):
+            ref = O.low_high_pass_filter(img.astype(np.float64), lp, hp)
+            np.testing.assert_allclose(H.low_high_pass_filter(img, lp, hp), ref, rtol=0, atol=2e-6 * np.abs(img).max())
     with pytest.raises(ValueError):
-        H.low_high_pass_filter(np.zeros((48, 48)))          # not a supported side
+        H.low_high_pass_filter(np.zeros((4, 4)))            # sides below 8
     with pytest.raises(NotImplementedError):
         H.low_high_pass_filter(np.zeros((32, 32, 32)))
     with pytest.raises(ValueError):

@@ -146,3 +146,18 @@ def test_g4b_linear_matrices_and_scores(golden_dir):
         if tw == 29.0:
             assert A.cosine_similarity(rec.ravel(), g["helix_rec3d_29"].ravel()) > 0.995   # same map, loosely converged
     assert int(np.argmax(got)) == int(np.argmax(g["helix_scores"])) == 1
+
+
+def test_g9_task_function_scores(golden_dir):
+    """Fixture G9 (the reference's process_one_task on a 32 x 48 helix): the oracle's lsq_reconstruct on the box sizes
+    the reference derived reproduces its cosine scores and maps (nearest neighbour; the low-passed, thresholded
+    case 3 is covered on the device, where the whole preparation runs)."""
+    g = np.load(golden_dir / "g9_process_one_task.npz")
+    for k in (0, 1):
+        tw, rs, cs, interp, thr, a3, td, lp = g[f"case{k}_args"]
+        d2, d3, l2, l3 = (int(v) for v in g[f"case{k}_dims"])
+        (rec, _, _), score = A.lsq_reconstruct(g["image"], 1.0, tw, rs / a3, int(cs), reconstruct_diameter_2d_pixel=d2,
+                                               reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2,
+                                               reconstruct_length_3d_pixel=l3, sym_oversample=1, interpolation="nn")
+        assert score == pytest.approx(float(g[f"case{k}_score"][0]), abs=1e-4)
+        assert np.abs(rec - g[f"case{k}_rec3d"]).max() < 1e-2 * np.abs(g[f"case{k}_rec3d"]).max()
