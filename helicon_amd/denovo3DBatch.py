@@ -7,7 +7,12 @@ its interactive counterpart is ``run_denovo3D_reconstruction`` (src/helicon/webA
 descending, app.py:2521-2523) this driver reproduces without the Shiny UI.
 
     python -m helicon_amd.denovo3DBatch image.npy --apix 2.0 --twist 25 33 0.2 --rise 8 13 0.2 \\
-           --csym 1 --out scores.npz [--mask mask.npy] [--no-log] [--device 0] [--top 10]
+           --csym 1 --out scores.npz [--mask mask.npy] [--no-log] [--device 0] [--top 10] \
+           [--rescore 20 --tube-diameter 120 --interpolation linear]
+
+``--rescore K`` runs the reference's own scorer — the sparse least-squares reconstruction of pipeline.py:84-496,
+``process_one_task(..., algorithm={"scorer": "lsq"})`` — on the sweep's K best candidates of every image, from a
+thread pool like the app's (app.py:2473-2476), and reports them in the order of that score.
 
 Images are ``.npy`` arrays or MRC files/stacks (``[ny, nx]`` or ``[S, ny, nx]``, helical axis along x; square
 power-of-two sides 32…1024 run the tuned kernels, any other size in 8…1024 the runtime-sized ones); ``--index``
@@ -43,6 +48,10 @@ def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
     parser.add_argument("--device", type=int, default=0)
     parser.add_argument("--top", type=int, default=10, help="how many best candidates to print per image")
     parser.add_argument("--out", default=None, help=".npz with scores[S, C, T, R], twists, rises, csyms")
+    parser.add_argument("--rescore", type=int, default=0, help="re-score this many best candidates per image with the least-squares scorer")
+    parser.add_argument("--tube-diameter", type=float, default=None, help="Angstrom, for --rescore (default 0.8 * ny * apix)")
+    parser.add_argument("--interpolation", choices=("nn", "linear"), default="linear", help="for --rescore (the app's default: linear)")
+    parser.add_argument("--threads", type=int, default=8, help="for --rescore")
     return parser
 
 
@@ -82,10 +91,35 @@ def run(args) -> dict:
             "top": [dict(twist=float(res.grid.params[g, 0]), rise=float(res.grid.params[g, 1]),
                          csym=int(res.grid.params[g, 2]), score=float(flat[s, g])) for g in order],
         })
+    if args.rescore > 0:
+        for s in range(flat.shape[0]):
+            report["images"][s]["rescored"] = rescore(images[s], report["images"][s]["top"][: args.rescore], args)
     if args.out:
         np.savez_compressed(args.out, scores=res.scores, twists=twists, rises=rises, csyms=np.asarray(args.csym),
                             params=res.grid.params, valid=res.grid.valid)
     return report
+
+
+def rescore(image, candidates, args) -> list:
+    """The least-squares scorer on a list of sweep candidates (dicts with twist, rise, csym, score), best first."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .denovo3D import process_one_task
+
+    ny = image.shape[0]
+    tube_d = args.tube_diameter if args.tube_diameter is not None else 0.8 * ny * args.apix
+
+    def one(c):
+        # the 36 positional arguments of pipeline.py:84-121 (no rescale: target_apix2d = apix; voxel size = pixel size)
+        out = process_one_task(0, 1, image, "", 1, c["twist"], c["rise"], (c["rise"], c["rise"]), c["csym"], 0.0, (0, 0),
+                               0.0, 0, 0.0, 0, args.apix, "", 0, 0, 0, 0, args.apix, -1, -1, -1, tube_d, 0, -1, 1,
+                               args.interpolation, 0, 0, "cosine", {"model": "lsq", "scorer": "lsq", "device": args.device}, 0, 1)
+        return dict(twist=c["twist"], rise=c["rise"], csym=c["csym"], sweep_score=c["score"],
+                    lsq_score=None if out is None else float(out[0]))
+
+    with ThreadPoolExecutor(max_workers=max(1, args.threads)) as pool:
+        got = list(pool.map(one, candidates))
+    return sorted(got, key=lambda r: -(r["lsq_score"] if r["lsq_score"] is not None else -np.inf))
 
 
 def main(argv=None) -> int:
