@@ -1490,7 +1490,11 @@ __device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b, fl
   const int count = hit ? (32 - __clz((int)hit)) - first : 0;
   cg += first;
   if ((x & 3) == 0 && count > 0) atomicMax(kc_s, count);
-  for (int k = 0; k < a.kg; ++k) {
+  __syncthreads();
+  // only the rows the fused pass will walk are written (at least one: a candidate that reaches no column still gets a
+  // row of zeros); what the buffer holds beyond them is never read
+  const int kc = *kc_s, kw = min(a.kg, max(kc, 1));
+  for (int k = 0; k < kw; ++k) {
     float wgt = 0.f;
     if (k < count) {
       const float xc = xc_tab[cg + k];
@@ -1502,11 +1506,10 @@ __device__ __forceinline__ void column_factors_of(const FactorArgs& a, int b, fl
   }
   int* const cgo = a.cgs + (size_t)b * cgs_stride<N>();
   if ((x & 3) == 0) cgo[x >> 2] = cg;
-  __syncthreads();
-  if (x < 4) cgo[N / 4 + x] = *kc_s;
+  if (x < 4) cgo[N / 4 + x] = kc;
 #if HH_POISON
   // sanitizer build: factor rows past the candidate's row count must never be read by the fused pass
-  for (int k = max(*kc_s, 1); k < a.kg; ++k) a.eg[((size_t)b * a.kg + k) * N + x] = __builtin_nanf("");
+  for (int k = kw; k < a.kg; ++k) a.eg[((size_t)b * a.kg + k) * N + x] = __builtin_nanf("");
 #endif
 }
 
