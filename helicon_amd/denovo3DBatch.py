@@ -52,6 +52,8 @@ def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
     parser.add_argument("--tube-diameter", type=float, default=None, help="Angstrom, for --rescore (default 0.8 * ny * apix)")
     parser.add_argument("--interpolation", choices=("nn", "linear"), default="linear", help="for --rescore (the app's default: linear)")
     parser.add_argument("--threads", type=int, default=8, help="for --rescore")
+    parser.add_argument("--map-out", default=None, help="for --rescore: write the best candidate's helically symmetrised map of every "
+                        "image to <map-out>_<image>.mrc (the app's map download, app.py:1267-1287)")
     return parser
 
 
@@ -94,6 +96,8 @@ def run(args) -> dict:
     if args.rescore > 0:
         for s in range(flat.shape[0]):
             report["images"][s]["rescored"] = rescore(images[s], report["images"][s]["top"][: args.rescore], args)
+            if args.map_out and report["images"][s]["rescored"]:
+                report["images"][s]["map"] = write_best_map(images[s], report["images"][s]["rescored"][0], args, f"{args.map_out}_{s}.mrc")
     if args.out:
         np.savez_compressed(args.out, scores=res.scores, twists=twists, rises=rises, csyms=np.asarray(args.csym),
                             params=res.grid.params, valid=res.grid.valid)
@@ -120,6 +124,24 @@ def rescore(image, candidates, args) -> list:
     with ThreadPoolExecutor(max_workers=max(1, args.threads)) as pool:
         got = list(pool.map(one, candidates))
     return sorted(got, key=lambda r: -(r["lsq_score"] if r["lsq_score"] is not None else -np.inf))
+
+
+def write_best_map(image, best, args, path) -> str:
+    """app.py:1267-1287: the candidate's least-squares map, helically symmetrised onto the input's grid
+    (new_size = (nx, ny, ny) at the input's pixel size), as an MRC file."""
+    from .denovo3D import apply_helical_symmetry, process_one_task
+    from .mrc import write_mrc
+
+    ny, nx = image.shape
+    tube_d = args.tube_diameter if args.tube_diameter is not None else 0.8 * ny * args.apix
+    out = process_one_task(0, 1, image, "", 1, best["twist"], best["rise"], (best["rise"], best["rise"]), best["csym"], 0.0, (0, 0),
+                           0.0, 0, 0.0, 0, args.apix, "", 0, 0, 0, 0, args.apix, -1, -1, -1, tube_d, 0, -1, 1, args.interpolation,
+                           0, 1, "cosine", {"model": "lsq", "scorer": "lsq", "device": args.device}, 0, 1)
+    rec3d, apix3d = out[1][3][0], out[2][3]
+    vol = apply_helical_symmetry(rec3d, apix3d, best["twist"], best["rise"], best["csym"], 1.0, (nx, ny, ny), args.apix,
+                                 device=args.device).astype(np.float32)
+    write_mrc(path, vol, args.apix)
+    return str(path)
 
 
 def main(argv=None) -> int:

@@ -243,7 +243,7 @@ def test_batch_driver_rescores_the_best_sweep_candidates(tmp_path):
     args = B.add_args(argparse.ArgumentParser()).parse_args(
         [str(tmp_path / "img.npy"), "--apix", str(apix), "--twist", "27", "31", "0.5", "--rise", "18", "22", "1", "--top", "6",
          "--helical-diameter", str(0.5 * ny * apix), "--rescore", "6", "--tube-diameter", str(0.7 * ny * apix), "--interpolation", "nn",
-         "--threads", "3"])
+         "--threads", "3", "--map-out", str(tmp_path / "best")])
     rep = B.run(args)
     im = rep["images"][0]
     assert (im["best"]["twist"], im["best"]["rise"]) == (29.0, 20.0)
@@ -257,3 +257,9 @@ def test_batch_driver_rescores_the_best_sweep_candidates(tmp_path):
                                 0, apix, "", 0, 0, 0, 0, apix, -1, -1, -1, 0.7 * ny * apix, 0, -1, 1, "nn", 0, 0, "cosine",
                                 {"model": "lsq", "scorer": "lsq"}, 0, 1)
     assert direct[0] == c["lsq_score"] and direct[1][3] is None      # bit-reproducible; return_3d = 0 keeps the map out
+    from helicon_amd.mrc import read_mrc
+
+    vol, vox = read_mrc(im["map"])                                   # the app's map download: (nx, ny, ny) voxels at the input's pixel size
+    assert vol.shape == (nx, ny, ny) and vox == pytest.approx(apix) and np.isfinite(vol).all() and vol.max() > 0
+    proj = vol.sum(axis=2).T                                         # its projection along x looks like the input
+    assert A.cosine_similarity(proj.ravel(), np.clip(img, 0, None).ravel()) > 0.8
