@@ -1578,7 +1578,7 @@ struct KF {
 };
 
 template <int N, int EPI, int LOG>
-__global__ __launch_bounds__(N, (N >= 512 ? HH_KF_WPS : 1)) void k_fused_pass(FusedArgs a) {
+__global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(FusedArgs a) {
   using K = KF<N>;
   using KP = KB<N>;  // the partial-moment layout is k_second_pass's
   constexpr int T = K::T, TL = T < 64 ? T : 64, NKY = N / 2;
