@@ -1239,7 +1239,7 @@ __device__ __forceinline__ void group_sum3(float& a, float& b, float& c) {
 // candidate (that re-read cost as much L2 -> CU traffic as the intermediate itself).  Each row's
 // three moments are reduced inside its wavefront and written as one partial triple.
 template <int N, int EPI, int LOG>
-__global__ __launch_bounds__(KB<N>::THREADS, (N >= 512 ? KB<N>::WAVES_PER_SIMD : 1)) void k_second_pass(SecondArgs a) {
+__global__ __launch_bounds__(KB<N>::THREADS, (N >= 256 ? KB<N>::WAVES_PER_SIMD : 1)) void k_second_pass(SecondArgs a) {
   using K = KB<N>;
   constexpr int T = K::T, TL = T < 64 ? T : 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
