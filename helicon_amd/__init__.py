@@ -5,7 +5,7 @@ from .grid import (CandidateGrid, build_grid, layer_line_mask, radial_band_mask,
                    shard_bounds, sweep_axis)
 from .denovo3D import (SweepEngine, SweepResult, apply_helical_symmetry, compute_power_spectra, cosine_similarity,
                        cross_correlation_coefficient, is_vertical, low_high_pass_filter, process_one_task,
-                       rotate_shift_image, simulate_helical_projection, sweep, threshold_data)
+                       rotate_shift_image, simulate_helical_projection, sweep, threshold_data, transform_map)
 from ._lib import HeliconHipError
 from .solver import lsq_reconstruct
 

@@ -3916,6 +3916,97 @@ __global__ __launch_bounds__(256) void k_affine_bilinear(const float* __restrict
   }
   out[(size_t)y * nx + x] = v;
 }
+
+// ---- helicon.transform_map (lib/transforms.py:168-235): scipy.ndimage.map_coordinates(order = 3) of a volume ----------
+// Step 1, the B-spline prefilter (scipy.ndimage.spline_filter, ni_splines.c): along every axis in turn, the cubic spline's
+// one pole z = sqrt(3) - 2, gain (1 - z)(1 - 1/z), a causal and an anti-causal recursion with MIRROR initialisation
+// ("constant" is filtered like "mirror").  One thread per line; float64 like SciPy.
+__global__ __launch_bounds__(128) void k_spline_prefilter(double* __restrict__ c, int64_t n_lines, int len, int64_t inner,
+                                                          int64_t stride) {
+#pragma clang fp contract(off)
+  // line l of an axis with `inner` elements after it: first element at (l / inner) * len * inner + l % inner, step `stride`
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_lines || len < 2) return;
+  double* const p = c + (l / inner) * (int64_t)len * inner + l % inner;
+  const double z = sqrt(3.0) - 2.0;
+  const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+  for (int i = 0; i < len; ++i) p[i * stride] *= gain;
+  const double zn1 = pow(z, (double)(len - 1));
+  double c0 = p[0] + zn1 * p[(int64_t)(len - 1) * stride];
+  double zi = z;
+  for (int i = 1; i < len - 1; ++i) {
+    c0 = c0 + zi * (p[i * stride] + zn1 * p[(int64_t)(len - 1 - i) * stride]);
+    zi *= z;
+  }
+  p[0] = c0 / (1.0 - zn1 * zn1);
+  for (int i = 1; i < len; ++i) p[i * stride] += z * p[(i - 1) * stride];
+  p[(int64_t)(len - 1) * stride] = (z * p[(int64_t)(len - 2) * stride] + p[(int64_t)(len - 1) * stride]) * z / (z * z - 1.0);
+  for (int i = len - 2; i >= 0; --i) p[i * stride] = z * (p[(i + 1) * stride] - p[i * stride]);
+}
+
+struct MapArgs {
+  int nz, ny, nx;
+  double m[9];            // rotation (row-major): p = m (X, Y, Z)
+  double scale;
+  double ox, oy, oz;      // nx // 2 - dx, ny // 2 - dy, nz // 2 - dz
+};
+
+__device__ __forceinline__ int spline_mirror(int idx, int n) {  // tap index outside [0, n - 1]: mirrored about the end points
+  if (n <= 1) return 0;
+  const int s2 = 2 * n - 2;
+  idx = abs(idx) % s2;
+  return idx >= n ? s2 - idx : idx;
+}
+
+// Step 2: output voxel (k, j, i) samples the coefficient volume at m ((i - nx/2), (j - ny/2), (k - nz/2)) scale + offset:
+// 0 if the point leaves [0, n - 1] on any axis, else the 4 x 4 x 4 cubic B-spline taps (weights as ni_interpolation.c
+// forms them: the last one by subtraction), summed z-outer, x-inner.
+__global__ __launch_bounds__(256) void k_map_cubic(const double* __restrict__ c, MapArgs a, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.nz * a.ny * a.nx;
+  if (t >= total) return;
+  const int i = (int)(t % a.nx), j = (int)((t / a.nx) % a.ny), k = (int)(t / ((int64_t)a.nx * a.ny));
+  double X = (double)(i - a.nx / 2), Y = (double)(j - a.ny / 2), Z = (double)(k - a.nz / 2);
+  if (a.scale != 1.0) { X *= a.scale; Y *= a.scale; Z *= a.scale; }
+  const double px = a.m[0] * X + a.m[1] * Y + a.m[2] * Z + a.ox;
+  const double py = a.m[3] * X + a.m[4] * Y + a.m[5] * Z + a.oy;
+  const double pz = a.m[6] * X + a.m[7] * Y + a.m[8] * Z + a.oz;
+  float v = 0.f;
+  if (pz >= 0.0 && pz <= (double)(a.nz - 1) && py >= 0.0 && py <= (double)(a.ny - 1) && px >= 0.0 && px <= (double)(a.nx - 1)) {
+    const double cc[3] = {pz, py, px};
+    const int dims[3] = {a.nz, a.ny, a.nx};
+    double w[3][4];
+    int id[3][4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double f = floor(cc[d]);
+      const double y = cc[d] - f, zc = 1.0 - y;
+      w[d][1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+      w[d][2] = (zc * zc * (zc - 2.0) * 3.0 + 4.0) / 6.0;
+      w[d][0] = zc * zc * zc / 6.0;
+      w[d][3] = 1.0 - w[d][0] - w[d][1] - w[d][2];
+      const int start = (int)f - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) id[d][q] = spline_mirror(start + q, dims[d]);
+    }
+    double acc = 0.0;
+    for (int q0 = 0; q0 < 4; ++q0)
+      for (int q1 = 0; q1 < 4; ++q1) {
+        const double* const row = c + ((int64_t)id[0][q0] * a.ny + id[1][q1]) * a.nx;
+        const double w01 = w[0][q0] * w[1][q1];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) acc += row[id[2][q2]] * (w01 * w[2][q2]);
+      }
+    v = (float)acc;
+  }
+  out[t] = v;
+}
+
+__global__ void k_f32_to_f64(const float* __restrict__ in, int64_t n, double* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = (double)in[t];
+}
 }  // namespace
 
 extern "C" {
@@ -3942,6 +4033,61 @@ int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const 
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_affine_transform_2d: ") + hipGetErrorString(e));
+  return HH_OK;
+}
+
+int hh_transform_map(int device, const float* data, const int32_t shape[3], double scale, double rot_degree, double tilt_degree,
+                     double psi_degree, double dx, double dy, double dz, float* out) {
+  if (!data || !out || !shape || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+    return fail(nullptr, HH_ERR_ARG, "hh_transform_map: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, HH_ERR_HIP, "hh_transform_map: no such HIP device (there is no CPU fallback)");
+  const int nz = shape[0], ny = shape[1], nx = shape[2];
+  const int64_t total = (int64_t)nz * ny * nx;
+  MapArgs a{};
+  a.nz = nz; a.ny = ny; a.nx = nx;
+  a.scale = scale;
+  a.ox = (double)(nx / 2) - dx;
+  a.oy = (double)(ny / 2) - dy;
+  a.oz = (double)(nz / 2) - dz;
+  {  // intrinsic "ZYZ" Euler angles (scipy Rotation.from_euler("ZYZ", (rot, tilt, psi))): Rz(rot) Ry(tilt) Rz(psi)
+    const double d2r = M_PI / 180.0;
+    const double c1 = std::cos(rot_degree * d2r), s1 = std::sin(rot_degree * d2r), c2 = std::cos(tilt_degree * d2r),
+                 s2 = std::sin(tilt_degree * d2r), c3 = std::cos(psi_degree * d2r), s3 = std::sin(psi_degree * d2r);
+    const double rz1[9] = {c1, -s1, 0, s1, c1, 0, 0, 0, 1}, ry[9] = {c2, 0, s2, 0, 1, 0, -s2, 0, c2}, rz3[9] = {c3, -s3, 0, s3, c3, 0, 0, 0, 1};
+    double t[9];
+    for (int r = 0; r < 3; ++r)
+      for (int cidx = 0; cidx < 3; ++cidx) t[3 * r + cidx] = rz1[3 * r] * ry[cidx] + rz1[3 * r + 1] * ry[3 + cidx] + rz1[3 * r + 2] * ry[6 + cidx];
+    for (int r = 0; r < 3; ++r)
+      for (int cidx = 0; cidx < 3; ++cidx) a.m[3 * r + cidx] = t[3 * r] * rz3[cidx] + t[3 * r + 1] * rz3[3 + cidx] + t[3 * r + 2] * rz3[6 + cidx];
+  }
+  float *d_in = nullptr, *d_out = nullptr;
+  double* d_c = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&d_in, (size_t)total * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)total * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_c, (size_t)total * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d_in, data, (size_t)total * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks), dim3(256), 0, 0, d_in, total, d_c);
+    // axis 0 (z), 1 (y), 2 (x), in SciPy's order: lines = the product of the other two sides
+    const int len[3] = {nz, ny, nx};
+    const int64_t inner[3] = {(int64_t)ny * nx, (int64_t)nx, 1};
+    for (int ax = 0; ax < 3; ++ax) {
+      const int64_t lines = total / len[ax];
+      hipLaunchKernelGGL(k_spline_prefilter, dim3((unsigned)((lines + 127) / 128)), dim3(128), 0, 0, d_c, lines, len[ax], inner[ax],
+                         inner[ax]);
+    }
+    hipLaunchKernelGGL(k_map_cubic, dim3(blocks), dim3(256), 0, 0, d_c, a, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)total * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  (void)hipFree(d_c);
+  if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_transform_map: ") + hipGetErrorString(e));
   return HH_OK;
 }
 

@@ -37,6 +37,7 @@ __all__ = [
     "threshold_data",
     "apply_helical_symmetry",
     "rotate_shift_image",
+    "transform_map",
     "is_vertical",
     "units_to_cylindrical",
 ]
@@ -512,6 +513,24 @@ def rotate_shift_image(data, angle=0, pre_shift=(0, 0), post_shift=(0, 0), rotat
     return out if d.dtype == np.float32 else out.astype(d.dtype if d.dtype.kind == "f" else np.float64)
 
 
+def transform_map(data, scale=1.0, rot=0, tilt=0, psi=0, dx=0, dy=0, dz=0, *, device=0):
+    """``helicon.transform_map`` (lib/transforms.py:168-235): scale, rotate (intrinsic ZYZ Euler angles, degrees) and
+    shift the sampling grid of a (nz, ny, nx) volume about its centre voxel and resample it like
+    ``scipy.ndimage.map_coordinates(order=3)`` — on the device (``hh_transform_map``).  With every argument at its
+    default the input itself is returned, like the reference."""
+    if scale == 1 and rot == 0 and tilt == 0 and psi == 0 and dx == 0 and dy == 0 and dz == 0:
+        return data
+    vol = np.ascontiguousarray(data, dtype=np.float32)
+    if vol.ndim != 3:
+        raise ValueError("data must be a 3D volume (nz, ny, nx)")
+    out = np.empty_like(vol)
+    shape = (C.c_int32 * 3)(*vol.shape)
+    _lib.check(_lib.lib().hh_transform_map(int(device), _ptr(vol, C.c_float), shape, float(scale), float(rot), float(tilt),
+                                           float(psi), float(dx), float(dy), float(dz), _ptr(out, C.c_float)), None)
+    d = np.asarray(data)
+    return out if d.dtype == np.float32 else out.astype(d.dtype if d.dtype.kind == "f" else np.float64)
+
+
 def is_vertical(data):
     """webApps/denovo3D/utils.py:429-447: the strongest column sum exceeds the strongest row sum."""
     d = np.asarray(data)
@@ -646,8 +665,6 @@ def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, cs
     dimensions, ``lsq_reconstruct``, helical symmetrisation back on the input's grid, projections and z sections."""
     from .solver import lsq_reconstruct
 
-    if tilt or psi or dy:
-        raise NotImplementedError("scorer 'lsq': tilt / psi / dy need the reference's cubic map_coordinates resampling of the map")
     # the image the reference would have at pipeline.py:286 (``prepared`` already went through the low pass, the
     # transpose and, with thresh_fraction >= 0, the background subtraction + threshold + / max), and its ``data_orig``
     img = np.asarray(prepared)
@@ -711,8 +728,9 @@ def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, cs
     pitch_pixel = int(360 / abs(tw_eff) * rise / apix + 0.5) if abs(tw_eff) > 1e-2 else int(np.ceil(2 * rise / apix))
     new_length = max(nx, int(pitch_pixel * 1.2))
     sym = apply_helical_symmetry(rec3d, a3, twist, rise, csym, new_size=(new_length, ny, ny), new_apix=apix, device=device)
-    x_proj = np.sum(sym, axis=2).T
-    y_proj = np.sum(sym, axis=1).T
+    tilted = transform_map(sym, scale=1.0, tilt=tilt, psi=psi, dy=dy / apix, device=device)   # pipeline.py:430-432
+    x_proj = np.sum(tilted, axis=2).T
+    y_proj = np.sum(tilted, axis=1).T
     y_max = y_proj.max()
     if y_max > 0:
         y_proj = y_proj * (x_proj.max() / y_max)
@@ -747,8 +765,8 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
     ``algorithm["scorer"] = "lsq"`` runs the reference's OWN scorer instead (pipeline.py:286-496): the sparse
     least-squares reconstruction on the device (``helicon_amd.lsq_reconstruct``, model "lsq", interpolation "nn" or
     "linear"), its cosine score, the helically symmetrised map (``apply_helical_symmetry``) and its x / y projections
-    and central z sections — the reference's complete return tuple.  Tilt, psi and dy must be zero there (the
-    reference resamples the map with a cubic ``map_coordinates`` otherwise).
+    and central z sections — the reference's complete return tuple (with tilt / psi / dy the projections are taken
+    from the map resampled by ``transform_map``, like the reference's).
 
     The reference's pool calls this once per (twist, rise) pair with the same image (app.py:2473-2476): the
     prepared image is cached by content, and the engine keeps the reference spectrum it was last given, so

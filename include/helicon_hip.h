@@ -13,6 +13,7 @@
  *   hh_cosine_similarity   lib/analysis.py:802-821            cosine_similarity
  *   hh_apply_helical_symmetry  lib/transforms.py:58-165       apply_helical_symmetry
  *   hh_affine_transform_2d lib/transforms.py:315-369          rotate_shift_image (its scipy.ndimage.affine_transform call)
+ *   hh_transform_map       lib/transforms.py:168-235          transform_map (Euler ZYZ + scipy.ndimage.map_coordinates, cubic)
  *   hh_set_reference +     webApps/denovo3D/app.py:2455-2523  reconstruction_task (the pool over
  *   hh_sweep[_device]                                         candidates) scoring each candidate by
  *                                                             cc(ref[mask], pwr[mask])
@@ -206,6 +207,15 @@ int hh_cosine_similarity_f64(hh_ctx* ctx, const double* a, const double* b, int6
  * (helicon_amd.rotate_shift_image shows it).  Context-free: errors are read with hh_last_error(NULL). */
 int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const double matrix[4], const double offset[2],
                            float* out);
+
+/* helicon.transform_map (lib/transforms.py:168-235; the reference's task function resamples the symmetrised map with
+ * it when tilt / psi / dy are not zero, pipeline.py:430-432): data is host float32 [shape[0]][shape[1]][shape[2]] (z, y, x);
+ * the sampling grid, centred on voxel (n // 2), is scaled, rotated by the intrinsic ZYZ Euler angles (rot, tilt, psi;
+ * degrees) and shifted by (dx, dy, dz), and the volume is resampled as scipy.ndimage.map_coordinates(order = 3) does:
+ * float64 B-spline prefilter with mirror boundaries, 4 x 4 x 4 cubic taps, 0 where the sample point leaves the volume.
+ * out: float32, same shape.  Context-free: errors are read with hh_last_error(NULL). */
+int hh_transform_map(int device, const float* data, const int32_t shape[3], double scale, double rot_degree, double tilt_degree,
+                     double psi_degree, double dx, double dy, double dz, float* out);
 
 /* Helical symmetrisation of a 3-D map (transforms.py:58-165): data is host float32
  * [in_shape[0]][in_shape[1]][in_shape[2]] (z, y, x); new_size / new_apix as in the reference (pass the

@@ -79,3 +79,98 @@ def apply_helical_symmetry(data, apix, twist_degree, rise_angstrom, csym=1, frac
                               ny // 2 - ny1 // 2: ny // 2 + ny1 // 2,
                               nx // 2 - nx1 // 2: nx // 2 + nx1 // 2]
     return data_work
+
+
+# ---- helicon.transform_map (lib/transforms.py:168-235) ------------------------------------------------------------------
+def _spline_prefilter_axis(c, axis):
+    """scipy.ndimage.spline_filter1d(order=3, mode="constant"): the cubic B-spline's one pole sqrt(3) - 2, causal and
+    anti-causal recursions with MIRROR initialisation (ni_splines.c treats "constant" like "mirror")."""
+    z = np.sqrt(3.0) - 2.0
+    c = np.moveaxis(np.array(c, dtype=np.float64), axis, 0)
+    n = c.shape[0]
+    if n < 2:
+        return np.moveaxis(c, 0, axis)
+    c *= (1.0 - z) * (1.0 - 1.0 / z)
+    zn1 = z ** (n - 1)
+    c0 = c[0] + zn1 * c[n - 1]
+    zi = z
+    for i in range(1, n - 1):
+        c0 = c0 + zi * (c[i] + zn1 * c[n - 1 - i])
+        zi *= z
+    c[0] = c0 / (1.0 - zn1 * zn1)
+    for i in range(1, n):
+        c[i] += z * c[i - 1]
+    c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0)
+    for i in range(n - 2, -1, -1):
+        c[i] = z * (c[i + 1] - c[i])
+    return np.moveaxis(c, 0, axis)
+
+
+def _mirror(idx, n):
+    if n <= 1:
+        return np.zeros_like(idx)
+    s2 = 2 * n - 2
+    idx = np.abs(idx) % s2
+    return np.where(idx >= n, s2 - idx, idx)
+
+
+def map_coordinates_cubic(data, coords):
+    """scipy.ndimage.map_coordinates(data, coords, order=3) with its defaults (mode="constant", cval=0, prefilter):
+    a point outside [0, n - 1] on any axis gives 0; inside, 4 x 4 x 4 cubic B-spline taps with mirrored indices."""
+    c = np.asarray(data, dtype=np.float64)
+    for ax in range(c.ndim):
+        c = _spline_prefilter_axis(c, ax)
+    coords = np.asarray(coords, dtype=np.float64)
+    shape = c.shape
+    inside = np.ones(coords.shape[1], dtype=bool)
+    for d in range(3):
+        inside &= (coords[d] >= 0) & (coords[d] <= shape[d] - 1)
+    out = np.zeros(coords.shape[1], dtype=np.float64)
+    cc = coords[:, inside]
+    idx, w = [], []
+    for d in range(3):
+        f = np.floor(cc[d])
+        y = cc[d] - f
+        zc = 1.0 - y
+        w1 = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0
+        w2 = (zc * zc * (zc - 2.0) * 3.0 + 4.0) / 6.0
+        w0 = zc * zc * zc / 6.0
+        w3 = 1.0 - w0 - w1 - w2
+        w.append((w0, w1, w2, w3))
+        start = f.astype(np.int64) - 1
+        idx.append([_mirror(start + t, shape[d]) for t in range(4)])
+    acc = np.zeros(cc.shape[1], dtype=np.float64)
+    for a in range(4):
+        for b in range(4):
+            for e in range(4):
+                acc += c[idx[0][a], idx[1][b], idx[2][e]] * (w[0][a] * w[1][b] * w[2][e])
+    out[inside] = acc
+    return out.astype(np.asarray(data).dtype if np.asarray(data).dtype.kind == "f" else np.float64)
+
+
+def transform_map(data, scale=1.0, rot=0, tilt=0, psi=0, dx=0, dy=0, dz=0):
+    """lib/transforms.py:168-235: rotate (intrinsic ZYZ Euler angles: Rz(rot) Ry(tilt) Rz(psi)), scale and shift the
+    sampling grid about the volume's centre voxel, resample with the cubic spline above."""
+    if scale == 1 and rot == 0 and tilt == 0 and psi == 0 and dx == 0 and dy == 0 and dz == 0:
+        return data
+    nz, ny, nx = data.shape
+    Z, Y, X = np.meshgrid(np.arange(nz, dtype=np.int32) - nz // 2, np.arange(ny, dtype=np.int32) - ny // 2,
+                          np.arange(nx, dtype=np.int32) - nx // 2, indexing="ij")
+    if scale != 1.0:
+        Z, Y, X = Z * scale, Y * scale, X * scale
+    xyz = np.vstack((X.ravel(), Y.ravel(), Z.ravel())).astype(np.float64)
+
+    def rz(a):
+        c, s = np.cos(np.deg2rad(a)), np.sin(np.deg2rad(a))
+        return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+    def ry(a):
+        c, s = np.cos(np.deg2rad(a)), np.sin(np.deg2rad(a))
+        return np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+
+    m = rz(rot) @ ry(tilt) @ rz(psi)
+    p = m @ xyz
+    p[0] += nx // 2 - dx
+    p[1] += ny // 2 - dy
+    p[2] += nz // 2 - dz
+    return map_coordinates_cubic(data, p[[2, 1, 0]]).reshape((nz, ny, nx))

@@ -442,10 +442,47 @@ def g9_process_one_task():
     np.savez_compressed(OUT / "g9_process_one_task.npz", **out)
 
 
+def g10_transform_map():
+    """helicon.transform_map (lib/transforms.py:168-235: Rotation.from_euler("ZYZ") + scipy map_coordinates, cubic) on
+    small volumes, and the reference's task function with tilt / psi / dy (the only place it resamples the map)."""
+    from helicon.webApps.denovo3D import pipeline
+
+    rng = np.random.default_rng(10)
+    out = {}
+    cases = [
+        # (shape, scale, rot, tilt, psi, dx, dy, dz)
+        ((12, 16, 20), 1.0, 0.0, 5.0, -7.0, 0.0, 1.5, 0.0),
+        ((10, 14, 14), 1.1, 30.0, 10.0, 20.0, 1.0, -2.0, 0.5),
+        ((9, 11, 13), 0.9, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+        ((16, 8, 8), 1.0, 0.0, 0.0, 12.0, 0.0, 0.0, 0.0),
+    ]
+    for k, (shape, sc, rot, tilt, psi, dx, dy, dz) in enumerate(cases):
+        vol = rng.normal(size=shape).astype(np.float32)
+        got = transforms.transform_map(vol, scale=sc, rot=rot, tilt=tilt, psi=psi, dx=dx, dy=dy, dz=dz)
+        out[f"case{k}_vol"] = vol
+        out[f"case{k}_args"] = np.array([sc, rot, tilt, psi, dx, dy, dz], dtype=np.float64)
+        out[f"case{k}_out"] = np.asarray(got)
+        print("g10 case", k, np.asarray(got).dtype, np.asarray(got).shape)
+    ny, nx, apix = 32, 48, 5.0
+    img = utils.simulate_helical_projection(n=1, twist=29.0, rise=10.0, csym=1, helical_diameter=60.0, ball_radius=10.0,
+                                            polymer=0, planarity=0, ny=ny, nx=nx, apix=apix, tilt=3.0, psi=2.0, dy=5.0)
+    img = np.asarray(img, dtype=np.float32)
+    out["task_image"] = img
+    score, ret, meta = pipeline.process_one_task(0, 1, img.copy(), "mem", 1, 29.0, 10.0, (10.0, 10.0), 1, 3.0, (0, 0), 2.0, 0, 5.0, 0,
+                                                 apix, "", 0, 0, 0, 5.0, apix, -1, -1, -1, 100.0, 0, -1, 1, "nn", 0, 1, "cosine",
+                                                 {"model": "lsq"}, 0, 1)
+    out["task_score"] = np.array([score])
+    out["task_x_proj"], out["task_y_proj"], out["task_z_sections"] = (np.asarray(v) for v in ret[:3])
+    out["task_rec3d"] = np.asarray(ret[3][0])
+    out["task_dims"] = np.array(ret[4:8], dtype=np.int64)
+    print("g10 task", score, ret[4:8])
+    np.savez_compressed(OUT / "g10_transform_map.npz", **out)
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift, g9_process_one_task]
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:
         if not only or make.__name__ in only:

@@ -221,9 +221,6 @@ def test_process_one_task_with_the_reference_scorer(golden_dir):
                 assert A.cosine_similarity(got.ravel(), want.ravel()) > 0.95, (k, name)
     # the score separates the true twist from its neighbour, as in the reference (cases 0 and 1)
     assert float(g["case0_score"][0]) > float(g["case1_score"][0])
-    with pytest.raises(NotImplementedError):
-        H.process_one_task(0, 1, img.copy(), "mem", 1, 29.0, 10.0, (10.0, 10.0), 1, 2.0, (0, 0), 0.0, 0, 0.0, 0, apix, "", 0, 0, 0,
-                           5.0, apix, -1, -1, -1, 100.0, 0, -1, 1, "nn", 0, 1, "cosine", {"model": "lsq", "scorer": "lsq"}, 0, 1)
 
 
 def test_batch_driver_rescores_the_best_sweep_candidates(tmp_path):
@@ -263,3 +260,34 @@ def test_batch_driver_rescores_the_best_sweep_candidates(tmp_path):
     assert vol.shape == (nx, ny, ny) and vox == pytest.approx(apix) and np.isfinite(vol).all() and vol.max() > 0
     proj = vol.sum(axis=2).T                                         # its projection along x looks like the input
     assert A.cosine_similarity(proj.ravel(), np.clip(img, 0, None).ravel()) > 0.8
+
+
+def test_transform_map_and_the_tilted_task(golden_dir):
+    """helicon.transform_map (lib/transforms.py:168-235: ZYZ Euler rotation of the sampling grid + scipy's cubic
+    map_coordinates) on the device against the reference's outputs (fixture G10): the B-spline prefilter with mirror
+    boundaries, the 64 taps and the zero outside — values to 2e-6 of the peak, the same voxels zero.  Then the reference's
+    task function with tilt, psi and dy, the one place where it resamples the map."""
+    import helicon_amd as H
+    from oracle import symmetrize as S
+
+    g = np.load(golden_dir / "g10_transform_map.npz")
+    for k in range(4):
+        sc, rot, tilt, psi, dx, dy, dz = g[f"case{k}_args"]
+        got = H.transform_map(g[f"case{k}_vol"], sc, rot, tilt, psi, dx, dy, dz)
+        want = g[f"case{k}_out"]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        np.testing.assert_array_equal(got == 0, want == 0)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max())
+    vol = np.random.default_rng(2).normal(size=(40, 33, 57)).astype(np.float32)
+    np.testing.assert_allclose(H.transform_map(vol, 1.0, 0, 4.0, -3.0, 0, 2.5, 0), S.transform_map(vol, 1.0, 0, 4.0, -3.0, 0, 2.5, 0),
+                               rtol=0, atol=2e-6 * np.abs(vol).max())
+    assert H.transform_map(vol) is vol                              # the reference's early return
+    img, apix = g["task_image"], 5.0
+    score, ret, meta = H.process_one_task(0, 1, img.copy(), "mem", 1, 29.0, 10.0, (10.0, 10.0), 1, 3.0, (0, 0), 2.0, 0, 5.0, 0, apix, "",
+                                          0, 0, 0, 5.0, apix, -1, -1, -1, 100.0, 0, -1, 1, "nn", 0, 1, "cosine",
+                                          {"model": "lsq", "scorer": "lsq"}, 0, 1)
+    assert tuple(ret[4:8]) == tuple(int(v) for v in g["task_dims"]) and meta[8:] == (3.0, 2.0, 5.0)
+    assert score == pytest.approx(float(g["task_score"][0]), abs=2e-4)
+    for got, name in ((ret[0], "x_proj"), (ret[1], "y_proj"), (ret[2], "z_sections"), (ret[3][0], "rec3d")):
+        want = g[f"task_{name}"]
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-2 * np.abs(want).max(), name
