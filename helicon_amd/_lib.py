@@ -55,7 +55,7 @@ class hh_pa_params(C.Structure):
         ("reconstruct_diameter_3d_pixel", C.c_int32), ("reconstruct_diameter_3d_inner_pixel", C.c_int32),
         ("reconstruct_length_3d_pixel", C.c_int32),
         ("min_projection_lines", C.c_int64), ("min_sym_pairs", C.c_int64),
-        ("interpolation", C.c_int32),
+        ("interpolation", C.c_int32), ("fsc_mode", C.c_int32), ("fsc_half", C.c_int32),
     ]
 
 

@@ -14,8 +14,8 @@ What runs where:
   :352-355) — the trust-region-reflective iteration of scipy/optimize/_lsq/trf_linear.py, O(n) vector arithmetic per
   outer iteration — plus the cosine score (:484-530) and the volume assembly (:532-547).
 
-Not in this slice (``NotImplementedError``): the scikit-learn models, half-set solves
-(``fsc_test``), tilt/psi/dy refinement, scores other than cosine.  There is no CPU fallback: without the library or a
+Not in this slice (``NotImplementedError``): the scikit-learn models, the random half-set split
+(``fsc_test=1``), tilt/psi/dy refinement, scores other than cosine.  There is no CPU fallback: without the library or a
 GPU the call raises.
 """
 from __future__ import annotations
@@ -66,7 +66,7 @@ class PathAProblem:
     def __init__(self, image, *, scale2d_to_3d, twist_degree, rise_pixel, csym, tilt_degree, psi_degree, dy_pixel,
                  reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, reconstruct_diameter_3d_pixel,
                  reconstruct_diameter_3d_inner_pixel, reconstruct_length_3d_pixel, min_projection_lines, min_sym_pairs,
-                 interpolation="nn", device=0):
+                 interpolation="nn", fsc_mode=0, fsc_half=0, device=0):
         self._L = _lib.lib()
         img = np.ascontiguousarray(image, dtype=np.float32)
         if img.ndim != 2:
@@ -75,7 +75,8 @@ class PathAProblem:
                          float(psi_degree), float(dy_pixel), int(reconstruct_diameter_2d_pixel),
                          int(reconstruct_length_2d_pixel), int(reconstruct_diameter_3d_pixel),
                          int(reconstruct_diameter_3d_inner_pixel), int(reconstruct_length_3d_pixel),
-                         int(min_projection_lines), int(min_sym_pairs), {"nn": 0, "linear": 1}[interpolation])
+                         int(min_projection_lines), int(min_sym_pairs), {"nn": 0, "linear": 1}[interpolation],
+                         int(fsc_mode), int(fsc_half))
         self._h = C.c_void_p()
         rc = self._L.hh_pa_create(C.byref(self._h), int(device), img.ctypes.data_as(C.POINTER(C.c_float)), img.shape[0],
                                   img.shape[1], C.byref(q))
@@ -349,7 +350,8 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
                     score_metric="cosine", target_apix2d=5.0, verbose=0, algorithm=dict(model="lsq"),
                     refine_tilt_psi_dy_range=None, cpu=1, *, device=0):
     """solver_linear_regression.py:31-547 for ``interpolation`` "nn" or "linear", ``algorithm["model"] == "lsq"``,
-    ``fsc_test=0``, cosine score: returns ``((rec3d float32 (L3d, D3d, D3d), None, None), score)``.
+    cosine score: returns ``((rec3d float32 (L3d, D3d, D3d), None, None), score)``, or with ``fsc_test`` 2, 3 or 4 the
+    maps of the two pixel halves as well and ``score = s_full / 2 + (s_half1 + s_half2) / 4``.
 
     The solve runs in float64 throughout.  With "linear" the reference's first LSMR call runs in float32 (its matrix is
     float32 and NumPy 2 keeps that type), so its score is reproducible to about 1e-3 only — the tolerance of the parity
@@ -358,8 +360,8 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
         raise ValueError("interpolation must be 'nn' or 'linear'")
     if (algorithm or {}).get("model", "lsq") != "lsq":
         raise NotImplementedError("the GPU slice of Path A provides model='lsq' (the scikit-learn models are not deterministic)")
-    if fsc_test:
-        raise NotImplementedError("half-set solves (fsc_test) are outside this slice")
+    if fsc_test == 1:
+        raise NotImplementedError("fsc_test=1 is the reference's random split of the pixels (np.random.shuffle of a set)")
     if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
         raise NotImplementedError("scores other than cosine need scikit-image")
     if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):
@@ -373,25 +375,36 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     mask = get_cylindrical_mask(l3, d3, d3, rmin=rmin, rmax=rmax)
     n3 = int(np.count_nonzero(mask))
     target = min(2**26, int(max(d2 * l2, n3) * sym_oversample))                   # solver:148-150, 168-170
-    with PathAProblem(img, scale2d_to_3d=scale2d_to_3d, twist_degree=twist_degree, rise_pixel=rise_pixel, csym=csym,
-                      tilt_degree=tilt_degree, psi_degree=psi_degree, dy_pixel=dy_pixel,
-                      reconstruct_diameter_2d_pixel=d2, reconstruct_length_2d_pixel=l2, reconstruct_diameter_3d_pixel=d3,
-                      reconstruct_diameter_3d_inner_pixel=reconstruct_diameter_3d_inner_pixel,
-                      reconstruct_length_3d_pixel=l3, min_projection_lines=target, min_sym_pairs=target,
-                      interpolation=interpolation, device=device) as P:
-        if P.n != n3:
-            raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
-                             "the 3-D diameter): the reference's two masks would rank the voxels differently")
-        b = np.concatenate((P.b_data.astype(np.float64), np.zeros(P.m_sym)))
-        pitch_pixel = round(rise_pixel * 360 / abs(twist_degree))
-        positive = positive_constraint > 0 or (positive_constraint < 0 and pitch_pixel > round(l3 * 2))   # solver:352-355
-        lb, ub = (0.0, float(np.max(P.b_data))) if positive else (-np.inf, np.inf)                        # solver:245-256
-        x, _, _ = _solve_bounded(P, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxiter=1000)
-        x = x.astype(np.float32)
-        pred = P.matvec(x.astype(np.float64))[: P.m_data]
-        if thresh_fraction >= 0:
-            pred = np.clip(pred, 0, None)
-        score = cosine_similarity(pred, P.b_data.astype(np.float64))
-    rec3d = np.zeros(mask.shape, dtype=np.float32)
-    rec3d[mask] = x
+    pitch_pixel = round(rise_pixel * 360 / abs(twist_degree))
+    positive = positive_constraint > 0 or (positive_constraint < 0 and pitch_pixel > round(l3 * 2))   # solver:352-355
+    xs, scores = [], []
+    # the whole image, then (fsc_test >= 2: solver:448-482) the two halves of its pixels, each with the same symmetry block
+    for half in ((0, 1, 2) if fsc_test and fsc_test > 1 else (0,)):
+        with PathAProblem(img, scale2d_to_3d=scale2d_to_3d, twist_degree=twist_degree, rise_pixel=rise_pixel, csym=csym,
+                          tilt_degree=tilt_degree, psi_degree=psi_degree, dy_pixel=dy_pixel,
+                          reconstruct_diameter_2d_pixel=d2, reconstruct_length_2d_pixel=l2, reconstruct_diameter_3d_pixel=d3,
+                          reconstruct_diameter_3d_inner_pixel=reconstruct_diameter_3d_inner_pixel,
+                          reconstruct_length_3d_pixel=l3, min_projection_lines=target, min_sym_pairs=target,
+                          interpolation=interpolation, fsc_mode=int(fsc_test) if half else 0, fsc_half=half, device=device) as P:
+            if P.n != n3:
+                raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
+                                 "the 3-D diameter): the reference's two masks would rank the voxels differently")
+            b = np.concatenate((P.b_data.astype(np.float64), np.zeros(P.m_sym)))
+            lb, ub = (0.0, float(np.max(P.b_data))) if positive else (-np.inf, np.inf)                    # solver:245-256
+            x, _, _ = _solve_bounded(P, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxiter=1000)
+            x = x.astype(np.float32)
+            pred = P.matvec(x.astype(np.float64))[: P.m_data]
+            if thresh_fraction >= 0:
+                pred = np.clip(pred, 0, None)
+            xs.append(x)
+            scores.append(cosine_similarity(pred, P.b_data.astype(np.float64)))
+    score = scores[0] / 2 + (scores[1] + scores[2]) / 4 if len(scores) == 3 else scores[0]                # solver:526-529
+    maps = []
+    for x in xs:
+        rec = np.zeros(mask.shape, dtype=np.float32)
+        rec[mask] = x
+        maps.append(rec)
+    if len(maps) == 3:
+        return (maps[0], maps[1], maps[2]), score
+    rec3d = maps[0]
     return (rec3d, None, None), score

@@ -264,6 +264,9 @@ typedef struct hh_pa_params {
   int64_t min_sym_pairs;          /* symmetry rows wanted (solver:1275); 0 = no symmetry block */
   int32_t interpolation;          /* 0 = "nn" (solver:1511-1553, 1142-1298), 1 = "linear" (solver:1414-1503, 910-1140:
                                      trilinear weights, rays recomputed in every product, 16-entry symmetry rows) */
+  int32_t fsc_mode, fsc_half;     /* half sets of lsq_reconstruct's fsc_test (split_A_b, solver:175-203): fsc_half 0 = all
+                                     data rows, 1 / 2 = the rows of the first / second half of the pixel ids under
+                                     fsc_mode 2 (every second id), 3 (lower / upper half), >= 4 (outer / middle thirds) */
 } hh_pa_params;
 int hh_pa_create(hh_pa** out, int device, const float* image, int ny, int nx, const hh_pa_params* params);
 void hh_pa_destroy(hh_pa* pa);

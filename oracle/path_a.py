@@ -742,7 +742,7 @@ def cosine_similarity(a, b):
 def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, csym=1, tilt_degree=0, psi_degree=0,
                     dy_pixel=0, thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                     reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
-                    reconstruct_length_3d_pixel=-1, sym_oversample=1, interpolation="nn", return_parts=False):
+                    reconstruct_length_3d_pixel=-1, sym_oversample=1, interpolation="nn", return_parts=False, fsc_test=0):
     """``algorithm=dict(model="lsq")``, ``fsc_test=0``, ``score_metric="cosine"``: ((rec3d, None, None), score)."""
     rmin = reconstruct_diameter_3d_inner_pixel / 2
     rmax = reconstruct_diameter_3d_pixel // 2 - 1
@@ -774,6 +774,29 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     score = cosine_similarity(pred, b_data)
     rec3d = np.zeros(mask.shape, dtype=np.float32)
     rec3d[mask] = x
+    if fsc_test and fsc_test > 1:
+        # split_A_b (solver:175-203), deterministic modes: the rows of every second pixel id (2), of the lower half of the
+        # ids (3), of the outer thirds (4+) against the rest; each half is solved with the same symmetry block and its
+        # own upper bound; score = s0 / 2 + (s1 + s2) / 4 (solver:526-529)
+        ids = sorted(set(b_pid.tolist()))
+        n = len(ids)
+        set1 = ids[::2] if fsc_test == 2 else ids[: n // 2] if fsc_test == 3 else ids[: n // 3] + ids[n * 2 // 3:]
+        is1 = np.isin(b_pid, set1)
+        halves, scores = [], [score]
+        for sel in (is1, ~is1):
+            Ah, bh = A_data[sel], b_data[sel]
+            Af = vstack((Ah, A_hsym)).tocsr() if A_hsym is not None else Ah
+            bf = np.concatenate((bh, b_hsym)) if A_hsym is not None else bh
+            lbh, ubh = (0.0, float(np.max(bh))) if positive else (-np.inf, np.inf)
+            xh = lsq_linear_trf(Af, bf, lbh, ubh, tol=1e-2, max_iter=200, lsmr_maxiter=1000)[0].astype(np.float32)
+            ph = Ah.dot(xh)
+            if thresh_fraction >= 0:
+                ph = np.clip(ph, 0, None)
+            scores.append(cosine_similarity(ph, bh))
+            rh = np.zeros(mask.shape, dtype=np.float32)
+            rh[mask] = xh
+            halves.append(rh)
+        return (rec3d, halves[0], halves[1]), scores[0] / 2 + (scores[1] + scores[2]) / 4
     if return_parts:
         return (rec3d, None, None), score, dict(A_data=A_data, b_data=b_data, b_pid=b_pid, A_hsym=A_hsym, x=x, mask=mask)
     return (rec3d, None, None), score

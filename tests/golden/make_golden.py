@@ -479,10 +479,28 @@ def g10_transform_map():
     np.savez_compressed(OUT / "g10_transform_map.npz", **out)
 
 
+def g11_fsc_halves():
+    """lsq_reconstruct with fsc_test 2, 3, 4 (solver:448-482, 526-547): the maps of the two pixel halves and the
+    combined score s0 / 2 + (s1 + s2) / 4, on the helix of fixture G9."""
+    from helicon.webApps.denovo3D.solver_linear_regression import lsq_reconstruct
+
+    g9 = np.load(OUT / "g9_process_one_task.npz")
+    img = g9["image"]
+    out = {"image": img}
+    for mode in (2, 3, 4):
+        (rec, r1, r2), score = lsq_reconstruct(img, 1.0, 29.0, 2.0, 1, reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20,
+                                               reconstruct_length_2d_pixel=48, reconstruct_length_3d_pixel=6, sym_oversample=1,
+                                               interpolation="nn", fsc_test=mode, algorithm={"model": "lsq"})
+        out[f"mode{mode}_score"] = np.array([score])
+        out[f"mode{mode}_rec"], out[f"mode{mode}_rec1"], out[f"mode{mode}_rec2"] = rec, r1, r2
+        print("g11 mode", mode, score)
+    np.savez_compressed(OUT / "g11_fsc_halves.npz", **out)
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map]
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:
         if not only or make.__name__ in only:

@@ -291,3 +291,33 @@ def test_transform_map_and_the_tilted_task(golden_dir):
     for got, name in ((ret[0], "x_proj"), (ret[1], "y_proj"), (ret[2], "z_sections"), (ret[3][0], "rec3d")):
         want = g[f"task_{name}"]
         assert got.shape == want.shape and np.abs(got - want).max() < 1e-2 * np.abs(want).max(), name
+
+
+def test_half_set_solves_reproduce_the_reference(golden_dir):
+    """lsq_reconstruct(fsc_test = 2, 3, 4) (solver:175-203, 448-482, 526-547; fixture G11): the data rows of each half of
+    the image's pixels are selected inside hh_pa_create (fsc_mode / fsc_half), every half is solved with the same
+    symmetry block; combined score to 1e-4, the three maps to 1 % of their peak.  fsc_test = 1 is the reference's random
+    split and is refused."""
+    g = np.load(golden_dir / "g11_fsc_halves.npz")
+    kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=48,
+              reconstruct_length_3d_pixel=6, sym_oversample=1, interpolation="nn")
+    for mode in (2, 3, 4):
+        (rec, r1, r2), score = lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=mode, **kw)
+        assert score == pytest.approx(float(g[f"mode{mode}_score"][0]), abs=1e-4)
+        for got, name in ((rec, "rec"), (r1, "rec1"), (r2, "rec2")):
+            want = g[f"mode{mode}_{name}"]
+            assert got.shape == want.shape and np.abs(got - want).max() < 1e-2 * np.abs(want).max(), (mode, name)
+    with pytest.raises(NotImplementedError):
+        lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **kw)
+    # the halves partition the data rows
+    from helicon_amd.solver import PathAProblem
+    base = dict(scale2d_to_3d=1.0, twist_degree=29.0, rise_pixel=2.0, csym=1, tilt_degree=0, psi_degree=0, dy_pixel=0,
+                reconstruct_diameter_2d_pixel=20, reconstruct_length_2d_pixel=48, reconstruct_diameter_3d_pixel=20,
+                reconstruct_diameter_3d_inner_pixel=0, reconstruct_length_3d_pixel=6, min_projection_lines=960, min_sym_pairs=960)
+    with PathAProblem(g["image"], **base) as P0, PathAProblem(g["image"], fsc_mode=3, fsc_half=1, **base) as P1, \
+            PathAProblem(g["image"], fsc_mode=3, fsc_half=2, **base) as P2:
+        assert P1.m_data + P2.m_data == P0.m_data and P1.m_sym == P2.m_sym == P0.m_sym
+        assert sorted(np.r_[P1.b_pid, P2.b_pid].tolist()) == sorted(P0.b_pid.tolist())
+        assert not set(P1.b_pid.tolist()) & set(P2.b_pid.tolist())
+    with pytest.raises(ValueError):
+        PathAProblem(g["image"], fsc_mode=1, fsc_half=1, **base)

@@ -161,3 +161,17 @@ def test_g9_task_function_scores(golden_dir):
                                                reconstruct_length_3d_pixel=l3, sym_oversample=1, interpolation="nn")
         assert score == pytest.approx(float(g[f"case{k}_score"][0]), abs=1e-4)
         assert np.abs(rec - g[f"case{k}_rec3d"]).max() < 1e-2 * np.abs(g[f"case{k}_rec3d"]).max()
+
+
+def test_g11_half_set_solves(golden_dir):
+    """lsq_reconstruct(fsc_test = 2, 3, 4): the reference's combined score and its three maps (whole image, two pixel
+    halves) from the oracle's restatement of split_A_b."""
+    g = np.load(golden_dir / "g11_fsc_halves.npz")
+    for mode in (2, 3, 4):
+        (rec, r1, r2), score = A.lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, reconstruct_diameter_2d_pixel=20,
+                                                 reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=48,
+                                                 reconstruct_length_3d_pixel=6, sym_oversample=1, interpolation="nn", fsc_test=mode)
+        assert score == pytest.approx(float(g[f"mode{mode}_score"][0]), abs=1e-4)
+        for got, name in ((rec, "rec"), (r1, "rec1"), (r2, "rec2")):
+            want = g[f"mode{mode}_{name}"]
+            assert np.abs(got - want).max() < 1e-2 * np.abs(want).max(), (mode, name)
