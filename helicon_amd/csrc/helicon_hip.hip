@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   // it & 1 in round it, the copies for it + 1 go to the other buffer, one workgroup barrier closes the round.
   constexpr bool STAGGER = HH_KF_STAGGER && T == 64;
   constexpr int KCUT = (HH_KF_CUT < Plan<NF>::n) ? HH_KF_CUT : 1;  // A ends at the exchange after this stage
-  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4;
+  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(tid >> 6) >= (N / 64) / 2;
   if (HH_KF_PRIO && late) __builtin_amdgcn_s_setprio(HH_KF_PRIO);
 
   auto part_a = [&](int cc) {
@@ -1723,51 +1723,54 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     // A lane owns two groups of four consecutive columns (x = 4 t + c and 4 (t + T) + c): two independent
     // accumulation chains, and the operands of the next table row are in flight while this row's FMAs issue.
     {
-      const int xg0 = t, xg1 = t + T;
-      const float2* const grow0 = gs + gi * a.rows_lds + cgc[xg0];
-      const float2* const grow1 = gs + gi * a.rows_lds + cgc[xg1];
-      const float* const erow0 = egc + 4 * xg0;
-      const float* const erow1 = egc + 4 * xg1;
       // table rows this candidate needs (<= kg; a wave-uniform LDS word written by the factor kernel)
       // (clamped to the buffer's kg: whatever the word holds, the walk is bounded)
       // (at least one: a candidate that reaches no column has a first factor row of zeros, so the sums need no
       // separate zero fill)
       const int kgn = (HH_ABLATE & 2048) ? 0 : max(1, min(a.kg, __builtin_amdgcn_readfirstlane(cgc[N / 4])));
-      // The first table row initialises the sums (no zero fill), the others accumulate; the operand addresses are
-      // base + k x constant, so the unrolled loop addresses them with instruction offsets.
+      // sums of the two column groups xg0, xg1 (four columns each).  The first table row initialises the sums (no zero
+      // fill), the others accumulate; the operand addresses are base + k x constant, so the unrolled loop addresses
+      // them with instruction offsets.
       float2 p0, p1, p2, p3, q0, q1, q2, q3;
-      if (!(HH_ABLATE & 2048)) {
-        {
-          const float2 ga = grow0[0], gb = grow1[0];
-          const float4 ea = *reinterpret_cast<const float4*>(erow0), eb = *reinterpret_cast<const float4*>(erow1);
-          p0 = make_float2(ea.x * ga.x, ea.x * ga.y); p1 = make_float2(ea.y * ga.x, ea.y * ga.y);
-          p2 = make_float2(ea.z * ga.x, ea.z * ga.y); p3 = make_float2(ea.w * ga.x, ea.w * ga.y);
-          q0 = make_float2(eb.x * gb.x, eb.x * gb.y); q1 = make_float2(eb.y * gb.x, eb.y * gb.y);
-          q2 = make_float2(eb.z * gb.x, eb.z * gb.y); q3 = make_float2(eb.w * gb.x, eb.w * gb.y);
-        }
+      auto accumulate = [&](int xg0, int xg1) {
+        const float2* const grow0 = gs + gi * a.rows_lds + cgc[xg0];
+        const float2* const grow1 = gs + gi * a.rows_lds + cgc[xg1];
+        const float* const erow0 = egc + 4 * xg0;
+        const float* const erow1 = egc + 4 * xg1;
+        if (!(HH_ABLATE & 2048)) {
+          {
+            const float2 ga = grow0[0], gb = grow1[0];
+            const float4 ea = *reinterpret_cast<const float4*>(erow0), eb = *reinterpret_cast<const float4*>(erow1);
+            p0 = make_float2(ea.x * ga.x, ea.x * ga.y); p1 = make_float2(ea.y * ga.x, ea.y * ga.y);
+            p2 = make_float2(ea.z * ga.x, ea.z * ga.y); p3 = make_float2(ea.w * ga.x, ea.w * ga.y);
+            q0 = make_float2(eb.x * gb.x, eb.x * gb.y); q1 = make_float2(eb.y * gb.x, eb.y * gb.y);
+            q2 = make_float2(eb.z * gb.x, eb.z * gb.y); q3 = make_float2(eb.w * gb.x, eb.w * gb.y);
+          }
 #pragma unroll 2
-        for (int k = 1; k < kgn; ++k) {
-          const float2 ga = grow0[k], gb = grow1[k];
-          const float4 ea = *reinterpret_cast<const float4*>(erow0 + (size_t)k * N);
-          const float4 eb = *reinterpret_cast<const float4*>(erow1 + (size_t)k * N);
-          p0.x = fmaf(ea.x, ga.x, p0.x); p0.y = fmaf(ea.x, ga.y, p0.y);
-          p1.x = fmaf(ea.y, ga.x, p1.x); p1.y = fmaf(ea.y, ga.y, p1.y);
-          p2.x = fmaf(ea.z, ga.x, p2.x); p2.y = fmaf(ea.z, ga.y, p2.y);
-          p3.x = fmaf(ea.w, ga.x, p3.x); p3.y = fmaf(ea.w, ga.y, p3.y);
-          q0.x = fmaf(eb.x, gb.x, q0.x); q0.y = fmaf(eb.x, gb.y, q0.y);
-          q1.x = fmaf(eb.y, gb.x, q1.x); q1.y = fmaf(eb.y, gb.y, q1.y);
-          q2.x = fmaf(eb.z, gb.x, q2.x); q2.y = fmaf(eb.z, gb.y, q2.y);
-          q3.x = fmaf(eb.w, gb.x, q3.x); q3.y = fmaf(eb.w, gb.y, q3.y);
+          for (int k = 1; k < kgn; ++k) {
+            const float2 ga = grow0[k], gb = grow1[k];
+            const float4 ea = *reinterpret_cast<const float4*>(erow0 + (size_t)k * N);
+            const float4 eb = *reinterpret_cast<const float4*>(erow1 + (size_t)k * N);
+            p0.x = fmaf(ea.x, ga.x, p0.x); p0.y = fmaf(ea.x, ga.y, p0.y);
+            p1.x = fmaf(ea.y, ga.x, p1.x); p1.y = fmaf(ea.y, ga.y, p1.y);
+            p2.x = fmaf(ea.z, ga.x, p2.x); p2.y = fmaf(ea.z, ga.y, p2.y);
+            p3.x = fmaf(ea.w, ga.x, p3.x); p3.y = fmaf(ea.w, ga.y, p3.y);
+            q0.x = fmaf(eb.x, gb.x, q0.x); q0.y = fmaf(eb.x, gb.y, q0.y);
+            q1.x = fmaf(eb.y, gb.x, q1.x); q1.y = fmaf(eb.y, gb.y, q1.y);
+            q2.x = fmaf(eb.z, gb.x, q2.x); q2.y = fmaf(eb.z, gb.y, q2.y);
+            q3.x = fmaf(eb.w, gb.x, q3.x); q3.y = fmaf(eb.w, gb.y, q3.y);
+          }
+        } else {
+          p0 = p1 = p2 = p3 = q0 = q1 = q2 = q3 = make_float2(0.f, 0.f);
         }
-      } else {
-        p0 = p1 = p2 = p3 = q0 = q1 = q2 = q3 = make_float2(0.f, 0.f);
-      }
+      };
       // The row is handed to the transform through the group's exchange buffer.  A lane stores 2 x 32 bytes at a
       // 32-byte lane stride: the eight lanes of a ds_write_b128 group would hit four bank groups twice, so the
       // 16-byte chunk c = x / 2 lives at c ^ ((c >> 3) & 1) (chunks 2 xg, 2 xg + 1 of lanes xg and xg + 4 then fall
       // into different halves of the 128-byte bank span); the reader un-swizzles with one precomputed base.
       auto chunk = [](int c) { return HH_KF_PSWZ ? (c ^ ((c >> 3) & 1)) : c; };
       if constexpr (SPLIT) {
+        accumulate(t, t + T);
         // the radix-2 step, then y0 into the row's first half and y1 into its second (chunks 2 t, 2 t + 1 of each)
         const float2 d0 = csub(p0, q0), d1 = csub(p1, q1), d2 = csub(p2, q2), d3 = csub(p3, q3);
         p0 = cadd(p0, q0); p1 = cadd(p1, q1); p2 = cadd(p2, q2); p3 = cadd(p3, q3);
@@ -1781,6 +1784,8 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         y1[chunk(2 * t)] = make_float4(q0.x, q0.y, q1.x, q1.y);
         y1[chunk(2 * t + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
       } else {
+        const int xg0 = t, xg1 = t + T;
+        accumulate(xg0, xg1);
         float4* const row4 = reinterpret_cast<float4*>(buf);
         row4[chunk(2 * xg0)] = make_float4(p0.x, p0.y, p1.x, p1.y);
         row4[chunk(2 * xg0 + 1)] = make_float4(p2.x, p2.y, p3.x, p3.y);
@@ -1788,8 +1793,10 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         row4[chunk(2 * xg1 + 1)] = make_float4(q2.x, q2.y, q3.x, q3.y);
       }
     }
-    group_sync<T>();  // (SPLIT: the one workgroup barrier of the transform; an LDS-counter meeting of just the row's two
-                      // wavefronts was tried and lost 3.5 %)
+    // (SPLIT: the one workgroup barrier of the transform.  Tried and dropped: an LDS-counter meeting of just the row's
+    // two wavefronts, -3.5 %; every wavefront building its own half's input from all the row's columns — twice the
+    // accumulation, no barrier, stagger possible — -16 %)
+    group_sync<T>();
     float2 v[8];
     if constexpr (SPLIT) {  // n = tf + 64 m of the wavefront's own half
       const int ps = HH_KF_PSWZ ? ((((tf >> 1) ^ ((tf >> 4) & 1)) << 1) | (tf & 1)) : tf;
