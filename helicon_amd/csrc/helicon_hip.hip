@@ -3387,6 +3387,15 @@ void hh_destroy(hh_ctx* c) {
 
 int hh_max_batch(const hh_ctx* c) { return c ? c->max_batch : HH_ERR_ARG; }
 
+// The fused pass's launch plan for `runs` runs of `run_len` candidates, `n_kb` ky blocks and `slots` resident workgroups
+// (pure host arithmetic, no device needed): out = {runs_a, groups_a, cpw_a, groups_b, cpw_b, layers}.
+int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]) {
+  if (!out || runs < 1 || run_len < 1 || n_kb < 1 || slots < 1) return HH_ERR_ARG;
+  const FusedSchedule fs = fused_schedule(runs, run_len, n_kb, slots);
+  out[0] = fs.runs_a; out[1] = fs.groups_a; out[2] = fs.cpw_a; out[3] = fs.groups_b; out[4] = fs.cpw_b; out[5] = fs.layers;
+  return HH_OK;
+}
+
 int hh_set_stream(hh_ctx* c, void* hip_stream) {
   if (!c) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));

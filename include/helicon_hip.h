@@ -99,6 +99,12 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch);
 void hh_destroy(hh_ctx* ctx);
 /* candidates per kernel launch this context was created with (the resolved default). */
 int hh_max_batch(const hh_ctx* ctx);
+/* How hh_sweep cuts a launch of the fused pipeline into workgroups: `runs` runs of `run_len`
+ * candidates, `n_kb` ky blocks, `slots` workgroups resident on the device at a time.  The first runs_a runs are cut into
+ * groups_a layers of cpw_a candidates each, the others into groups_b layers of cpw_b; out = {runs_a, groups_a, cpw_a,
+ * groups_b, cpw_b, layers}.  Pure host arithmetic (the reference has no counterpart: its pool takes one task per candidate,
+ * app.py:2473-2476); exported so the plan can be inspected and tested without a device. */
+int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]);
 /* ctx may be NULL: returns the message of the last failed hh_create on this thread. */
 const char* hh_last_error(const hh_ctx* ctx);
 

@@ -282,3 +282,37 @@ def test_no_process_wide_kernel_attribute_flags():
     """hipFuncAttributeMaxDynamicSharedMemorySize is per device: the library tracks it per context."""
     src = (ROOT / "helicon_amd" / "csrc" / "helicon_hip.hip").read_text()
     assert "static bool attr_done" not in src and "ensure_lds_attr" in src
+
+
+def test_fused_launch_schedule_covers_every_candidate_once():
+    """hh_fused_schedule (pure host arithmetic, loads without a GPU): whatever the shape, the plan's layers cover each run's
+    candidates exactly once, workgroups hold at least 16 candidates unless the run is shorter, and the cases DESIGN.md
+    quotes come out as quoted (C2 in one launch: whole runs, 25 rounds; an eighth of it: 48 whole runs + 2 runs in 8)."""
+    import ctypes as C
+
+    from helicon_amd import _lib
+
+    L = _lib.lib()
+
+    def plan(runs, run_len, n_kb, slots):
+        out = (C.c_int32 * 6)()
+        assert L.hh_fused_schedule(runs, run_len, n_kb, slots, out) == 0
+        return tuple(out)
+
+    assert plan(400, 250, 32, 512) == (400, 1, 250, 1, 250, 400)
+    ra, ga, ca, gb, cb, layers = plan(50, 250, 32, 512)
+    assert (ra, ga, ca) == (48, 1, 250) and gb == 8 and cb == 32 and layers == 48 + 2 * 8
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        runs, run_len = int(rng.integers(1, 3000)), int(rng.integers(1, 5000))
+        n_kb, slots = int(rng.integers(1, 65)), int(rng.choice([256, 512, 1024, 2048]))
+        ra, ga, ca, gb, cb, layers = plan(runs, run_len, n_kb, slots)
+        assert 0 <= ra <= runs and ga >= 1 and gb >= 1 and ca >= 1 and cb >= 1
+        assert layers == ra * ga + (runs - ra) * gb
+        for g, c in ((ga, ca), (gb, cb)):                       # g layers of c candidates cover a run, none is empty
+            assert g * c >= run_len and (g - 1) * c < run_len
+            assert c >= min(16, run_len) or g == 1
+        # the last region's workgroups are never longer than the first region's
+        assert cb <= ca
+    out = (C.c_int32 * 6)()
+    assert L.hh_fused_schedule(0, 10, 1, 512, out) != 0 and L.hh_fused_schedule(5, 10, 1, 0, out) != 0
