@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-__all__ = ["HeliconHipError", "lib", "lib_path", "hh_geom", "hh_profile", "hh_pa_params", "check", "EXPORTS"]
+__all__ = ["HeliconHipError", "lib", "lib_path", "hip_runtime_paths", "hh_geom", "hh_profile", "hh_pa_params", "check", "EXPORTS"]
 
 _HERE = Path(__file__).resolve().parent
 
@@ -122,11 +122,82 @@ EXPORTS = {
 }
 
 _lib = None
+_runtime = None  # path of the HIP runtime this process is bound to (diagnostics: hip_runtime_path())
 
 
 def lib_path() -> Path:
     env = os.environ.get("HELICON_HIP_LIB")
     return Path(env) if env else _HERE / "libhelicon_hip.so"
+
+
+def _mapped(fragment: str):
+    """Paths of the shared objects mapped into this process whose name contains `fragment`."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if fragment in path and path not in found:
+                    found.append(path)
+    except OSError:
+        pass
+    return found
+
+
+def _bind_hip_runtime() -> None:
+    """One HIP runtime per process, whatever the import order.
+
+    libhelicon_hip.so asks the loader for ``libamdhip64.so.7`` (the soname).  PyTorch's ROCm wheels ship their OWN copy of
+    the runtime in ``torch/lib`` and ask for it as ``libamdhip64.so`` (and ``libhsa-runtime64.so``).  glibc matches a
+    request against loaded objects by requested name or soname, so:
+
+    * torch first, this library second: ``libamdhip64.so.7`` matches the soname of torch's copy — one runtime;
+    * this library first, ``import torch`` later: ``libamdhip64.so`` matches neither the name nor the soname of the
+      system copy already loaded, torch maps its own — TWO HIP runtimes and TWO HSA runtimes in the process.  The second
+      one to initialise cannot open the device, and torch reports "No HIP GPUs are available" (round 2 saw exactly that
+      in test sessions whose first torch.cuda use came after the library's; tests/conftest.py papered over it by
+      initialising torch first).
+
+    So before the library is loaded, and only if no HIP runtime is mapped yet, the runtime of an INSTALLED torch (found
+    without importing it) is loaded by path: both this library (by soname) and a later ``import torch`` (same file: the
+    loader recognises the inode) then bind to it.  ``HELICON_HIP_RUNTIME=system`` keeps the system runtime instead,
+    ``HELICON_HIP_RUNTIME=/path/to/libamdhip64.so`` names one.
+    """
+    global _runtime
+    mapped = _mapped("libamdhip64")
+    if mapped:  # someone (torch, another extension) got there first: the soname match binds us to it
+        _runtime = mapped[0]
+        return
+    choice = os.environ.get("HELICON_HIP_RUNTIME", "auto")
+    if choice == "system":
+        return
+    path = None
+    if choice not in ("auto", "torch"):
+        path = Path(choice)
+    else:
+        import importlib.util
+
+        try:
+            spec = importlib.util.find_spec("torch")  # locates the package, does not import it
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.origin:
+            cand = Path(spec.origin).resolve().parent / "lib" / "libamdhip64.so"
+            if cand.exists():
+                path = cand
+    if path is None:
+        return
+    try:
+        C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+        _runtime = str(path)
+    except OSError as e:
+        raise HeliconHipError(f"cannot load the HIP runtime {path}: {e} (set HELICON_HIP_RUNTIME=system to use "
+                              "the one libhelicon_hip.so was linked against)") from e
+
+
+def hip_runtime_paths():
+    """Every libamdhip64 mapped into the process right now (more than one entry is the two-runtime condition)."""
+    return _mapped("libamdhip64")
 
 
 def lib():
@@ -140,6 +211,7 @@ def lib():
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); helicon_amd has no CPU fallback"
         )
+    _bind_hip_runtime()
     try:
         handle = C.CDLL(str(path))
     except OSError as e:  # e.g. libamdhip64 missing

@@ -1554,12 +1554,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // conservative s_waitcnt vmcnt(0) in front of the next ds_read, which serialises the copy with the transform it is
 // meant to fly under.  Here the compiler does not see the LDS write at all, so the CALLER orders it: s_waitcnt
 // vmcnt(0) (lds_dma_wait) and then a workgroup barrier before any wave reads the destination.
+// (M0 is a reserved register, which clang warns about on a clobber list; the clobber is still what tells the backend's
+// M0-initialisation hoisting that the register does not survive this statement.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                :
                : "v"(gsrc_lane), "s"(lds_base)
-               : "memory");  // (M0 is a reserved register: the compiler sets it next to each of its own uses)
+               : "memory", "m0");  // M0 is written here: the compiler must not keep a value of its own in it across this
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) {  // wave-uniform LDS byte address as a scalar
   return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)(const_cast<void*>(p)));
@@ -3701,9 +3706,8 @@ struct Rccl {
 };
 Rccl* rccl(std::string& err) {
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;   // two threads may make their first hh_comm_* call together
+  std::call_once(once, [] {
     // the soname first: a process that already holds RCCL (torch.distributed's "nccl" backend) gets that same copy
     for (const char* name : {"librccl.so.1", "librccl.so"})
       if ((r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
@@ -3714,7 +3718,7 @@ Rccl* rccl(std::string& err) {
       r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
     }
-  }
+  });
   if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) {
     err = "librccl.so.1 is not loadable (the multi-GPU entry points need RCCL)";
     return nullptr;
@@ -3769,7 +3773,9 @@ int hh_comm_destroy(hh_ctx* c) {
   Rccl* r = rccl(err);
   if (r) {
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // a borrowed stream (hh_set_stream) may be gone by the time the context is torn down: only the library's own
+    // stream is waited for; a caller that queued a collective on ITS stream synchronises that stream itself
+    if (c->stream == c->own_stream && c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     (void)r->CommDestroy(c->comm);
   }
   c->comm = nullptr;

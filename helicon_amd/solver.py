@@ -40,17 +40,22 @@ def _p(a):
 
 
 def get_cylindrical_mask(nz, ny, nx, rmin=0, rmax=-1, return_xyz=False):
-    """lib/analysis.py:731-774 (host-side helper: the order of the unknowns is the C-order rank of this mask)."""
-    k = np.arange(0, nz, dtype=np.int32) - nz // 2
-    j = np.arange(0, ny, dtype=np.int32) - ny // 2
-    i = np.arange(0, nx, dtype=np.int32) - nx // 2
-    Z, Y, X = np.meshgrid(k, j, i, indexing="ij")
+    """The reference's cylinder (lib/analysis.py:731-774) — voxels whose centred (y, x) offset lies strictly inside radius
+    ``rmax`` (default ``ny // 2 - 1``) and, when ``0 < rmin < rmax``, on or outside ``rmin`` — as one 2-D disk repeated
+    along z.  The C-order rank of this mask is the order of the unknowns (the device ranks the same disk in
+    ``pa_mask_rank``)."""
     if rmax < 0:
         rmax = ny // 2 - 1
-    mask = X * X + Y * Y < rmax * rmax
+    oy, ox = np.ogrid[-(ny // 2): ny - ny // 2, -(nx // 2): nx - nx // 2]
+    radius2 = oy.astype(np.int64) ** 2 + ox.astype(np.int64) ** 2
+    disk = radius2 < rmax * rmax
     if 0 < rmin < rmax:
-        mask &= X * X + Y * Y >= rmin * rmin
-    return (mask, (Z, Y, X)) if return_xyz else mask
+        disk &= radius2 >= rmin * rmin
+    mask = np.repeat(disk[None, :, :], nz, axis=0)
+    if not return_xyz:
+        return mask
+    offsets = [np.arange(-(n // 2), n - n // 2, dtype=np.int32) for n in (nz, ny, nx)]
+    return mask, tuple(np.meshgrid(*offsets, indexing="ij"))
 
 
 def cosine_similarity(a, b):

@@ -1,5 +1,6 @@
 """Host-side logic (no GPU): grid construction, masks, sharding, and the library's exports."""
 import re
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -316,3 +317,55 @@ def test_fused_launch_schedule_covers_every_candidate_once():
         assert cb <= ca
     out = (C.c_int32 * 6)()
     assert L.hh_fused_schedule(0, 10, 1, 512, out) != 0 and L.hh_fused_schedule(5, 10, 1, 0, out) != 0
+
+
+_ORDER_PROBE = r"""
+import sys
+sys.path.insert(0, {root!r})
+order = {order!r}
+def load_lib():
+    from helicon_amd import _lib
+    _lib.lib()
+def load_torch():
+    import torch  # noqa: F401
+for step in order:
+    load_lib() if step == "lib" else load_torch()
+from helicon_amd import _lib
+hip = _lib.hip_runtime_paths()
+hsa = _lib._mapped("libhsa-runtime64")
+print("HIP", len(hip), "HSA", len(hsa), hip, hsa)
+"""
+
+
+@pytest.mark.parametrize("order", [("lib", "torch"), ("torch", "lib")])
+def test_one_hip_runtime_whatever_the_import_order(order):
+    """Round 2's "No HIP GPUs are available": libhelicon_hip.so loaded before torch used to leave TWO HIP (and HSA)
+    runtimes in the process — torch's wheel carries its own copy under another file name — and the second one to
+    initialise cannot open the device.  _lib._bind_hip_runtime() makes both orders end with one."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", _ORDER_PROBE.format(root=str(ROOT), order=order)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("HIP")][-1].split()
+    assert line[1] == "1" and line[3] == "1", out.stdout
+
+
+@pytest.mark.gpu
+def test_torch_works_after_the_library_has_used_the_device():
+    """The failing order of round 2, in a fresh process: create and destroy contexts through the C ABI FIRST, then import
+    torch and make its first allocation.  (tests/conftest.py used to hide this by initialising torch first.)"""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import helicon_amd as H\n"
+        "for n in (64, 128, (48, 96)):\n"
+        "    e = H.SweepEngine(n); e.set_geometry(apix=2.0, helical_diameter=40.0, ball_radius=4.0)\n"
+        "    img = e.simulate(29.0, 10.0, 1); e.close()\n"
+        "import torch\n"
+        "t = torch.arange(8, device='cuda').float().sum().item()\n"
+        "from helicon_amd import _lib\n"
+        "print('RUNTIMES', len(_lib.hip_runtime_paths()), 'SUM', t)\n" % str(ROOT))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "RUNTIMES 1 SUM 28.0" in out.stdout, out.stdout + out.stderr
