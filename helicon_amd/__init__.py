@@ -7,6 +7,6 @@ from .denovo3D import (SweepEngine, SweepResult, apply_helical_symmetry, compute
                        cross_correlation_coefficient, is_vertical, low_high_pass_filter, process_one_task,
                        rotate_shift_image, simulate_helical_projection, sweep, threshold_data, transform_map)
 from ._lib import HeliconHipError
-from .solver import lsq_reconstruct
+from .solver import lsq_reconstruct, lsq_reconstruct_batch
 
 __version__ = "0.1.0"

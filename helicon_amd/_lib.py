@@ -119,6 +119,15 @@ EXPORTS = {
     "hh_pa_rmatvec": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, _f64p]),
     "hh_pa_lsmr": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_int, _f64p,
                              C.POINTER(C.c_int), _f64p]),
+    # Path A, many candidates at once (helicon_amd/solver.py: lsq_reconstruct_batch)
+    "hh_pab_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(hh_pa_params), C.c_int]),
+    "hh_pab_destroy": (None, [C.c_void_p]),
+    "hh_pab_last_error": (C.c_char_p, [C.c_void_p]),
+    "hh_pab_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hh_pab_get_rhs": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.POINTER(C.c_int32)]),
+    "hh_pab_solve": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_double, C.c_int, C.c_int, _f32p, _f64p,
+                               C.POINTER(C.c_int32)]),
+    "hh_pab_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -28,12 +28,14 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -4263,3 +4265,4 @@ int hh_profile_get(hh_ctx* c, hh_profile* out) {
 }  // extern "C"
 
 #include "path_a_host.inc"  // Path A: host side and C ABI (hh_pa_*)
+#include "path_a_batch.inc"  // Path A for many candidates at once, device-resident solve (hh_pab_*)

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["lsq_reconstruct", "PathAProblem", "get_cylindrical_mask", "cosine_similarity"]
+__all__ = ["lsq_reconstruct", "lsq_reconstruct_batch", "PathAProblem", "PathABatch", "get_cylindrical_mask", "cosine_similarity"]
 
 EPS = np.finfo(float).eps
 
@@ -147,6 +147,76 @@ class PathAProblem:
         self._check(self._L.hh_pa_lsmr(self._h, _p(rhs), _p(d), _p(root), float(atol), float(btol), float(conlim),
                                        int(maxiter), _p(x), info, norms))
         return x, int(info[0]), int(info[1]), float(norms[0]), float(norms[1])
+
+
+class PathABatch:
+    """K candidates of one image and one reconstruction box, set up and solved together on the device (``hh_pab``):
+    what the reference's thread pool does one ``process_one_task`` at a time (app.py:2473-2476)."""
+
+    def __init__(self, image, params, device=0):
+        self._L = _lib.lib()
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        if img.ndim != 2:
+            raise ValueError("projection_image must be 2-D")
+        self.count = len(params)
+        arr = (hh_pa_params * self.count)(*params)
+        self._h = C.c_void_p()
+        rc = self._L.hh_pab_create(C.byref(self._h), int(device), img.ctypes.data_as(C.POINTER(C.c_float)), img.shape[0],
+                                   img.shape[1], arr, self.count)
+        if rc:
+            msg = self._L.hh_pab_last_error(None)
+            kind = ValueError if rc == -1 else _lib.HeliconHipError
+            raise kind(f"hh_pab_create error {rc}: {msg.decode() if msg else '?'}")
+        dims = (C.c_int64 * 5)()
+        rows = np.empty((self.count, 3), dtype=np.int64)
+        self._L.hh_pab_dims(self._h, dims, rows.ctypes.data_as(C.POINTER(C.c_int64)))
+        self.n = int(dims[1])
+        self.device_bytes = int(dims[4])
+        self.m_data, self.m_sym, self.n_ops = rows[:, 0].copy(), rows[:, 1].copy(), rows[:, 2].copy()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.hh_pab_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rhs(self, c):
+        b = np.empty(int(self.m_data[c]), dtype=np.float32)
+        pid = np.empty(int(self.m_data[c]), dtype=np.int32)
+        self._L.hh_pab_get_rhs(self._h, int(c), b.ctypes.data_as(C.POINTER(C.c_float)), pid.ctypes.data_as(C.POINTER(C.c_int32)))
+        return b, pid
+
+    def solve(self, positive, clip, tol=1e-2, max_iter=200, lsmr_maxiter=1000, want_x=True):
+        """``lsq_linear`` + cosine score for every candidate: (x float32 [K, n] or None, scores [K], info [K, 4])."""
+        pos = np.ascontiguousarray(np.broadcast_to(np.asarray(positive, dtype=np.int32), (self.count,)))
+        clp = np.ascontiguousarray(np.broadcast_to(np.asarray(clip, dtype=np.int32), (self.count,)))
+        x = np.empty((self.count, self.n), dtype=np.float32) if want_x else None
+        scores = np.empty(self.count, dtype=np.float64)
+        info = np.empty((self.count, 4), dtype=np.int32)
+        i32 = C.POINTER(C.c_int32)
+        rc = self._L.hh_pab_solve(self._h, pos.ctypes.data_as(i32), clp.ctypes.data_as(i32), float(tol), int(max_iter),
+                                  int(lsmr_maxiter), None if x is None else x.ctypes.data_as(C.POINTER(C.c_float)),
+                                  scores.ctypes.data_as(_f64p), info.ctypes.data_as(i32))
+        if rc:
+            msg = self._L.hh_pab_last_error(self._h)
+            raise _lib.HeliconHipError(f"libhelicon_hip (Path A batch) error {rc}: {msg.decode() if msg else '?'}")
+        return x, scores, info
+
+    def counters(self):
+        out = (C.c_int64 * 3)()
+        self._L.hh_pab_counters(self._h, out)
+        return {"launches": int(out[0]), "host_syncs": int(out[1]), "lsmr_iterations_queued": int(out[2])}
 
 
 # ---- scipy.optimize.lsq_linear(method="trf", lsq_solver="lsmr", lsmr_tol="auto") around the device operator ----------
@@ -348,6 +418,76 @@ def _solve_bounded(P: PathAProblem, b, lb, ub, tol=1e-2, max_iter=200, lsmr_maxi
     return x, (0 if status is None else status), it + 1
 
 
+def _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, reconstruct_diameter_3d_pixel,
+         reconstruct_length_3d_pixel, reconstruct_diameter_3d_inner_pixel, sym_oversample):
+    """The integer geometry of lsq_reconstruct's first lines (solver:116-173): sizes, the cylinder and the row target."""
+    d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
+    d2 = int(reconstruct_diameter_2d_pixel) if reconstruct_diameter_2d_pixel > 0 else img.shape[0]
+    l2 = int(reconstruct_length_2d_pixel) if reconstruct_length_2d_pixel > 0 else img.shape[1]
+    mask = get_cylindrical_mask(l3, d3, d3, rmin=reconstruct_diameter_3d_inner_pixel / 2, rmax=d3 // 2 - 1)
+    n3 = int(np.count_nonzero(mask))
+    target = min(2**26, int(max(d2 * l2, n3) * sym_oversample))                   # solver:148-150, 168-170
+    return d2, l2, d3, l3, mask, n3, target
+
+
+def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degree=0, psi_degree=0, dy_pixel=0,
+                          thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
+                          reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
+                          reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, return_3d=True, device=0,
+                          batch=256, stats=None):
+    """``lsq_reconstruct`` (solver_linear_regression.py:31-547; nearest-neighbour projector, model "lsq", cosine score)
+    for MANY (twist_degree, rise_pixel, csym) candidates of one image: the loop the reference's driver runs as a thread
+    pool over ``process_one_task`` (app.py:2473-2476).  ``candidates`` is a sequence of ``(twist, rise, csym)``; the
+    other arguments have the meaning and defaults of ``lsq_reconstruct``.  Up to ``batch`` candidates are set up and
+    solved together on the device (``hh_pab_*``): every LSMR iteration and every trust-region step is one launch for
+    all of them.  Returns ``[((rec3d, half1, half2), score), ...]`` in the order of ``candidates`` (maps are ``None``
+    with ``return_3d=False``).  ``stats``, if a dict, receives launch / synchronisation counters."""
+    img = np.asarray(projection_image)
+    cands = [(float(t), float(r), int(c)) for t, r, c in candidates]
+    if fsc_test == 1:
+        raise NotImplementedError("fsc_test=1 (random halves) goes through lsq_reconstruct")
+    d2, l2, d3, l3, mask, n3, target = _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel,
+                                            reconstruct_diameter_3d_pixel, reconstruct_length_3d_pixel,
+                                            reconstruct_diameter_3d_inner_pixel, sym_oversample)
+    halves = (0, 1, 2) if fsc_test and fsc_test > 1 else (0,)
+    per = len(halves)
+    out = []
+    step = max(1, int(batch) // per)
+    for lo in range(0, len(cands), step):
+        chunk = cands[lo: lo + step]
+        params, positive = [], []
+        for tw, rs, cs in chunk:
+            pitch_pixel = round(rs * 360 / abs(tw))
+            pos = positive_constraint > 0 or (positive_constraint < 0 and pitch_pixel > round(l3 * 2))    # solver:352-355
+            for half in halves:
+                params.append(hh_pa_params(float(scale2d_to_3d), tw, rs, cs, float(tilt_degree), float(psi_degree),
+                                           float(dy_pixel), d2, l2, d3, int(reconstruct_diameter_3d_inner_pixel), l3,
+                                           int(target), int(target), 0, int(fsc_test) if half else 0, half))
+                positive.append(1 if pos else 0)
+        with PathABatch(img, params, device=device) as B:
+            if B.n != n3:
+                raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
+                                 "the 3-D diameter): the reference's two masks would rank the voxels differently")
+            x, scores, info = B.solve(positive, 1 if thresh_fraction >= 0 else 0, want_x=return_3d)
+            if stats is not None:
+                c = B.counters()
+                for k, v in c.items():
+                    stats[k] = stats.get(k, 0) + v
+                stats["device_bytes"] = max(stats.get("device_bytes", 0), B.device_bytes)
+                stats.setdefault("info", []).extend(info.tolist())
+        for k in range(len(chunk)):
+            sc = scores[k * per: (k + 1) * per]
+            score = float(sc[0] / 2 + (sc[1] + sc[2]) / 4 if per == 3 else sc[0])                          # solver:526-529
+            maps = [None, None, None]
+            if return_3d:
+                for h in range(per):
+                    rec = np.zeros(mask.shape, dtype=np.float32)
+                    rec[mask] = x[k * per + h]
+                    maps[h] = rec
+            out.append(((maps[0], maps[1], maps[2]), score))
+    return out
+
+
 def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, csym=1, tilt_degree=0, psi_degree=0,
                     dy_pixel=0, thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                     reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
@@ -372,6 +512,11 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):
         raise NotImplementedError("tilt / psi / dy refinement is outside this slice")
     img = np.asarray(projection_image)
+    if interpolation == "nn":   # the device-resident solver (a batch of one, or of three with half sets)
+        return lsq_reconstruct_batch(img, scale2d_to_3d, [(twist_degree, rise_pixel, csym)], tilt_degree, psi_degree, dy_pixel,
+                                     thresh_fraction, positive_constraint, reconstruct_diameter_3d_inner_pixel,
+                                     reconstruct_diameter_2d_pixel, reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel,
+                                     reconstruct_length_3d_pixel, sym_oversample, fsc_test, device=device)[0]
     d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
     d2 = int(reconstruct_diameter_2d_pixel) if reconstruct_diameter_2d_pixel > 0 else img.shape[0]
     l2 = int(reconstruct_length_2d_pixel) if reconstruct_length_2d_pixel > 0 else img.shape[1]

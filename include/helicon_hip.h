@@ -290,6 +290,33 @@ int hh_pa_rmatvec(hh_pa* pa, const double* y, const double* d, const double* roo
 int hh_pa_lsmr(hh_pa* pa, const double* rhs, const double* d, const double* root, double atol, double btol, double conlim,
                int maxiter, double* x_out, int info[2], double norms[2]);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Path A for MANY candidates at once (round 3): K candidates of one image and one reconstruction box — the K tasks the
+ * reference's thread pool runs one by one (webApps/denovo3D/app.py:2473-2476 -> pipeline.py:351-404 ->
+ * solver_linear_regression.py:31-547) — set up together and solved together on the device: every LSMR iteration and
+ * every step of scipy.optimize.lsq_linear's trust-region-reflective loop (solver_linear_regression.py:258-269) is one
+ * launch for all K; the host only reads "is anyone still iterating?".  Nearest-neighbour projector (params[i]
+ * .interpolation == 0); the candidates differ in twist / rise / csym / tilt / psi / dy / fsc half and share the
+ * 2-D region, the 3-D box and the row targets' meaning. */
+typedef struct hh_pab hh_pab;
+int hh_pab_create(hh_pab** out, int device, const float* image, int ny, int nx, const hh_pa_params* params, int count);
+void hh_pab_destroy(hh_pab* pab);
+const char* hh_pab_last_error(const hh_pab* pab);
+/* dims = {candidates, unknowns, total data rows, total symmetry rows, device bytes held};
+ * rows (may be NULL): [count][3] = {data rows, symmetry rows, symmetry operations used} */
+int hh_pab_dims(const hh_pab* pab, int64_t dims[5], int64_t* rows);
+/* b and pixel id (k * D2d + j) of candidate c's data rows (solver:1548-1549) */
+int hh_pab_get_rhs(const hh_pab* pab, int c, float* b, int32_t* b_pid);
+/* lsq_linear(A_c, b_c, bounds = positive[c] ? (0, max b_c) : none, tol, max_iter, lsmr_maxiter, lsmr_tol="auto") for
+ * every candidate; x -> float32; score = cosine(A_data x [clipped at 0 when clip[c]], b) (solver:484-530).
+ * x_out: [count][unknowns] float32 or NULL; scores: [count]; info: [count][4] = {lsq_linear status, trust-region
+ * iterations, LSMR solves, LSMR iterations} or NULL. */
+int hh_pab_solve(hh_pab* pab, const int32_t* positive, const int32_t* clip, double tol, int max_iter, int lsmr_maxiter,
+                 float* x_out, double* scores, int32_t* info);
+/* counters of the last hh_pab_solve: {kernel launches, host synchronisations, LSMR iterations queued} */
+int hh_pab_counters(const hh_pab* pab, int64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""Path A for many candidates at once (hh_pab_*, helicon_amd.lsq_reconstruct_batch) against the reference's own
+lsq_reconstruct outputs (fixture G5), the NumPy / SciPy oracle, and itself: a candidate's result must not depend on
+which other candidates share its batch, nor on the run.  solver_linear_regression.py:31-547; app.py:2473-2476."""
+import numpy as np
+import pytest
+
+from helicon_amd.solver import PathABatch, PathAProblem, hh_pa_params, lsq_reconstruct, lsq_reconstruct_batch
+from oracle import path_a as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _helix_kw(g):
+    s2, rs, cs, d2, d3, l2, l3, ov = g["helix_args"]
+    return float(s2), float(rs), int(cs), dict(reconstruct_diameter_2d_pixel=int(d2), reconstruct_diameter_3d_pixel=int(d3),
+                                               reconstruct_length_2d_pixel=int(l2), reconstruct_length_3d_pixel=int(l3),
+                                               sym_oversample=ov)
+
+
+def test_batch_reproduces_the_reference_scores(golden_dir):
+    """G5's three twists in ONE batch: the reference's scores to 1e-4, the 29-degree volume to the solver's tolerance."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    s2, rs, cs, kw = _helix_kw(g)
+    cands = [(float(tw), rs, cs) for tw in g["helix_twists"]]
+    stats = {}
+    res = lsq_reconstruct_batch(g["helix_image"], s2, cands, stats=stats, **kw)
+    for (maps, score), want, tw in zip(res, g["helix_scores"], g["helix_twists"]):
+        assert score == pytest.approx(float(want), abs=1e-4), tw
+        if tw == 29.0:
+            assert np.abs(maps[0] - g["helix_rec3d_29"]).max() < 5e-3 * np.abs(g["helix_rec3d_29"]).max()
+    assert stats["launches"] > 0 and stats["host_syncs"] < stats["launches"] / 8    # the host only polls
+    assert all(st in (1, 2, 3, -1, 0) for st, *_ in stats["info"])
+
+
+def test_batch_composition_and_runs_do_not_change_a_candidate(golden_dir):
+    """The same candidate alone, among 2 others, among 11 others, twice: bit-identical scores and maps (no quantity of
+    a candidate depends on another's; every sum has one order)."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    s2, rs, cs, kw = _helix_kw(g)
+    twists = [25.0 + 0.75 * k for k in range(12)]
+    big = lsq_reconstruct_batch(g["helix_image"], s2, [(t, rs, cs) for t in twists], **kw)
+    again = lsq_reconstruct_batch(g["helix_image"], s2, [(t, rs, cs) for t in twists], **kw)
+    small = lsq_reconstruct_batch(g["helix_image"], s2, [(t, rs, cs) for t in twists[4:7]], **kw)
+    split = lsq_reconstruct_batch(g["helix_image"], s2, [(t, rs, cs) for t in twists], batch=5, **kw)
+    for k in range(12):
+        assert big[k][1] == again[k][1] == split[k][1]
+        np.testing.assert_array_equal(big[k][0][0], again[k][0][0])
+        np.testing.assert_array_equal(big[k][0][0], split[k][0][0])
+    for k in range(3):
+        assert small[k][1] == big[4 + k][1]
+        np.testing.assert_array_equal(small[k][0][0], big[4 + k][0][0])
+    one = lsq_reconstruct(g["helix_image"], s2, twists[5], rs, cs, **kw)
+    assert one[1] == big[5][1]
+    np.testing.assert_array_equal(one[0][0], big[5][0][0])
+
+
+def test_batch_against_the_oracle_with_mixed_candidates(golden_dir):
+    """Candidates that differ in twist, rise AND csym, bounded and unbounded, clipped prediction: each equals the oracle's
+    lsq_reconstruct (scores 1e-4; the unbounded ones 1e-5, they are a single LSMR solve)."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    img = g["helix_image"]
+    kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=32,
+              reconstruct_length_3d_pixel=6)
+    cands = [(29.0, 2.0, 1), (31.0, 2.5, 1), (58.0, 4.0, 2), (-29.0, 2.0, 1), (27.5, 1.7, 1)]
+    for pc, tol in ((-1, 1e-4), (0, 1e-5), (1, 1e-4)):
+        res = lsq_reconstruct_batch(img, 1.0, cands, positive_constraint=pc, thresh_fraction=0.0, **kw)
+        for (maps, score), (tw, rs, cs) in zip(res, cands):
+            (rec_o, _, _), s_o = A.lsq_reconstruct(img, 1.0, tw, rs, cs, positive_constraint=pc, thresh_fraction=0.0, **kw)
+            assert score == pytest.approx(s_o, abs=tol), (pc, tw, rs, cs)
+            assert np.abs(maps[0] - rec_o).max() < 1e-2 * max(1e-6, np.abs(rec_o).max()), (pc, tw, rs, cs)
+
+
+def test_batch_rows_equal_the_single_candidate_problem(golden_dir):
+    """The batch's set-up (rays that exist, b, pixel ids, symmetry pairs) is the single-candidate hh_pa's, candidate by
+    candidate, including the half sets."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    img = np.ascontiguousarray(g["helix_image"], dtype=np.float32)
+    base = dict(scale2d_to_3d=1.0, csym=1, tilt_degree=2.0, psi_degree=1.0, dy_pixel=0.5, reconstruct_diameter_2d_pixel=20,
+                reconstruct_length_2d_pixel=32, reconstruct_diameter_3d_pixel=20, reconstruct_diameter_3d_inner_pixel=4,
+                reconstruct_length_3d_pixel=6, min_projection_lines=700, min_sym_pairs=700)
+    specs = [(29.0, 2.0, 0, 0), (31.0, 2.5, 3, 1), (31.0, 2.5, 3, 2), (27.0, 1.5, 2, 1)]
+    params = [hh_pa_params(1.0, tw, rs, 1, 2.0, 1.0, 0.5, 20, 32, 20, 4, 6, 700, 700, 0, mode, half) for tw, rs, mode, half in specs]
+    with PathABatch(img, params) as B:
+        for c, (tw, rs, mode, half) in enumerate(specs):
+            with PathAProblem(img, twist_degree=tw, rise_pixel=rs, fsc_mode=mode, fsc_half=half, **base) as P:
+                assert (B.n, int(B.m_data[c]), int(B.m_sym[c]), int(B.n_ops[c])) == (P.n, P.m_data, P.m_sym, P.n_ops)
+                b, pid = B.rhs(c)
+                np.testing.assert_array_equal(b, P.b_data)
+                np.testing.assert_array_equal(pid, P.b_pid)
+
+
+def test_batch_rejects_what_it_does_not_do():
+    img = np.ones((16, 16), dtype=np.float32)
+    ok = hh_pa_params(1.0, 29.0, 2.0, 1, 0.0, 0.0, 0.0, 12, 16, 12, 0, 4, 100, 100, 0, 0, 0)
+    lin = hh_pa_params(1.0, 29.0, 2.0, 1, 0.0, 0.0, 0.0, 12, 16, 12, 0, 4, 100, 100, 1, 0, 0)
+    other_box = hh_pa_params(1.0, 29.0, 2.0, 1, 0.0, 0.0, 0.0, 12, 16, 10, 0, 4, 100, 100, 0, 0, 0)
+    with pytest.raises(ValueError):
+        PathABatch(img, [ok, lin])
+    with pytest.raises(ValueError):
+        PathABatch(img, [ok, other_box])
+    with pytest.raises(NotImplementedError):
+        lsq_reconstruct_batch(img, 1.0, [(29.0, 2.0, 1)], fsc_test=1, reconstruct_diameter_3d_pixel=12, reconstruct_length_3d_pixel=4)

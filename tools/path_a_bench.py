@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Path A on the GPU (helicon_amd.lsq_reconstruct) at the size the reference app works at after its binning to
-target_apix2d (a 64 x 128 pixel projection, 64-voxel cylinder): set-up and solve times, nearest neighbour and trilinear,
-with the CPU oracle's time for the same call beside them (`--oracle`; minutes)."""
+"""Path A on the GPU at the size the reference app works at after its binning to target_apix2d (a 64 x 128 pixel
+projection, 64-voxel cylinder): the batched device-resident solver (helicon_amd.lsq_reconstruct_batch, nearest
+neighbour) over K candidates, set-up and solve timed apart, with its launch / synchronisation counters and the bytes
+its products move; then the single-candidate calls (nn through a batch of one, trilinear through hh_pa), and with
+`--oracle` the CPU oracle's time for one call (seconds).  `--json` prints one JSON object (bench.py's path_a leg)."""
+import json
 import sys
 import time
 from pathlib import Path
@@ -10,52 +13,79 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import helicon_amd as H  # noqa: E402
-from helicon_amd.solver import PathAProblem, lsq_reconstruct  # noqa: E402
+from helicon_amd.solver import PathABatch, hh_pa_params, lsq_reconstruct, lsq_reconstruct_batch  # noqa: E402
+
+NY, NX, L3 = 64, 128, 16
+KW = dict(reconstruct_diameter_2d_pixel=NY, reconstruct_diameter_3d_pixel=NY, reconstruct_length_2d_pixel=NX,
+          reconstruct_length_3d_pixel=L3)
+
+
+def test_image():
+    eng = H.SweepEngine((NY, NX))
+    eng.set_geometry(apix=5.0, helical_diameter=0.5 * NY * 5.0, ball_radius=10.0)
+    return eng.simulate(29.0, 20.0, 1).astype(np.float32)
+
+
+def batch_run(image, k, repeat=2):
+    """K candidates around the truth (twist 27 .. 31 degrees, rise 4 px): returns timings and counters of the best run."""
+    twists = np.linspace(27.0, 31.0, k)
+    cands = [(float(t), 4.0, 1) for t in twists]
+    best = None
+    for _ in range(repeat):
+        target = NY * NX   # = max(d2 * l2, unknowns) here
+        params = [hh_pa_params(1.0, t, r, c, 0.0, 0.0, 0.0, NY, NX, NY, 0, L3, target, target, 0, 0, 0) for t, r, c in cands]
+        t0 = time.perf_counter()
+        B = PathABatch(image, params)
+        t1 = time.perf_counter()
+        _, scores, info = B.solve(np.ones(k, dtype=np.int32), 0, want_x=False)
+        t2 = time.perf_counter()
+        cnt = B.counters()
+        run = dict(k=k, setup_s=t1 - t0, solve_s=t2 - t1, total_s=t2 - t0, candidates_per_s=k / (t2 - t0),
+                   solve_candidates_per_s=k / (t2 - t1), unknowns=B.n, data_rows=int(B.m_data.mean()), sym_rows=int(B.m_sym.mean()),
+                   device_bytes=B.device_bytes, lsmr_iterations=int(info[:, 3].sum()), lsmr_solves=int(info[:, 2].sum()),
+                   outer_iterations=int(info[:, 1].sum()), best_twist=float(twists[int(np.argmax(scores))]),
+                   best_score=float(scores.max()), **cnt)
+        # bytes a product pair (A x, A^T y) moves per candidate: the compact map + the transposed lists + the pairs, once each
+        nnz = float(np.mean(B.m_data)) * NY
+        run["bytes_per_product_pair"] = nnz * 4 + (nnz + 2 * float(np.mean(B.m_sym))) * 4 + float(np.mean(B.m_sym)) * 8
+        # one LSMR iteration also streams its vectors: u (read + write), v (r + w), h, hbar, x (r + w each), v again
+        m = float(np.mean(B.m_data + B.m_sym))
+        run["bytes_per_lsmr_iteration"] = run["bytes_per_product_pair"] + 8 * (2 * m + 9 * B.n)
+        B.close()
+        if best is None or run["total_s"] < best["total_s"]:
+            best = run
+    return best
 
 
 def main():
-    ny, nx, l3 = 64, 128, 16
-    eng = H.SweepEngine((ny, nx))
-    eng.set_geometry(apix=5.0, helical_diameter=0.5 * ny * 5.0, ball_radius=10.0)
-    image = eng.simulate(29.0, 20.0, 1).astype(np.float32)
-    kw = dict(reconstruct_diameter_2d_pixel=ny, reconstruct_diameter_3d_pixel=ny, reconstruct_length_2d_pixel=nx,
-              reconstruct_length_3d_pixel=l3)
+    image = test_image()
+    lsq_reconstruct(image, 1.0, 29.0, 4.0, 1, interpolation="nn", **KW)   # warm (module load, first allocations)
+    runs = [batch_run(image, k) for k in ((256,) if "--json" in sys.argv else (1, 16, 64, 256, 512))]
+    if "--json" in sys.argv:
+        print(json.dumps(runs[-1]))
+        return
+    for r in runs:
+        per_it = r["solve_s"] / max(1, r["lsmr_iterations"])
+        print(f"batch of {r['k']:4d}: set-up {r['setup_s'] * 1e3:7.1f} ms, solve {r['solve_s'] * 1e3:7.1f} ms -> "
+              f"{r['candidates_per_s']:7.1f} candidates/s ({r['solve_candidates_per_s']:.1f} solve only); unknowns {r['unknowns']}, "
+              f"rows {r['data_rows']} + {r['sym_rows']}; LSMR iterations {r['lsmr_iterations']} in {r['lsmr_solves']} solves, "
+              f"{r['outer_iterations']} trust-region iterations; {r['launches']} launches, {r['host_syncs']} host syncs, "
+              f"{r['lsmr_iterations_queued']} iterations queued; {per_it * 1e6:.2f} us per candidate-iteration = "
+              f"{r['bytes_per_lsmr_iteration'] / per_it / 1e12:.2f} TB/s of algorithmic traffic; device memory "
+              f"{r['device_bytes'] / 2**30:.2f} GiB; best twist {r['best_twist']:.3f} ({r['best_score']:.4f})", flush=True)
     for interp in ("nn", "linear"):
-        lsq_reconstruct(image, 1.0, 29.0, 4.0, 1, interpolation=interp, **kw)   # warm
         t0 = time.perf_counter()
-        P = PathAProblem(image, scale2d_to_3d=1.0, twist_degree=29.0, rise_pixel=4.0, csym=1, tilt_degree=0, psi_degree=0,
-                         dy_pixel=0, reconstruct_diameter_3d_inner_pixel=0, min_projection_lines=ny * nx,
-                         min_sym_pairs=ny * nx, interpolation=interp, **kw)
-        t_setup = time.perf_counter() - t0
-        x = np.random.default_rng(0).normal(size=P.n)
-        t0 = time.perf_counter()
-        for _ in range(20):
-            y = P.matvec(x)
-            P.rmatvec(y)
-        t_pair = (time.perf_counter() - t0) / 20
-        dims = (P.n, P.m_data, P.m_sym, P.n_ops)
-        P.close()
-        t0 = time.perf_counter()
-        scores = [lsq_reconstruct(image, 1.0, tw, 4.0, 1, interpolation=interp, **kw)[1] for tw in (27.0, 29.0, 31.0)]
+        scores = [lsq_reconstruct(image, 1.0, tw, 4.0, 1, interpolation=interp, **KW)[1] for tw in (27.0, 29.0, 31.0)]
         t_call = (time.perf_counter() - t0) / 3
-        print(f"{interp}: unknowns {dims[0]}, data rows {dims[1]}, symmetry rows {dims[2]}, operations {dims[3]}; set-up "
-              f"{t_setup * 1e3:.1f} ms, A x + A^T y (host vectors) {t_pair * 1e3:.2f} ms, lsq_reconstruct {t_call * 1e3:.1f} ms; "
-              f"scores at 27/29/31 deg {np.round(scores, 4)}", flush=True)
-    # the reference drives its scorer from a thread pool (app.py:2473-2476): calls on different candidates overlap on the
-    # device (one hh_pa and one stream each; ctypes releases the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-    twists = [27.0 + 0.25 * k for k in range(32)]
-    for threads in (1, 4, 8, 16):
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=threads) as pool:
-            scores = list(pool.map(lambda tw: lsq_reconstruct(image, 1.0, tw, 4.0, 1, interpolation="nn", **kw)[1], twists))
-        dt = time.perf_counter() - t0
-        print(f"nn, {len(twists)} candidates from {threads} thread(s): {len(twists) / dt:.1f} candidates/s; best twist "
-              f"{twists[int(np.argmax(scores))]}", flush=True)
+        print(f"{interp}: one lsq_reconstruct call {t_call * 1e3:.1f} ms; scores at 27/29/31 deg {np.round(scores, 4)}", flush=True)
+    t0 = time.perf_counter()
+    res = lsq_reconstruct_batch(image, 1.0, [(t, 4.0, 1) for t in np.linspace(27, 31, 100)], return_3d=True, **KW)
+    print(f"lsq_reconstruct_batch, 100 candidates with their maps: {time.perf_counter() - t0:.3f} s; best "
+          f"{np.linspace(27, 31, 100)[int(np.argmax([s for _, s in res]))]:.3f}", flush=True)
     if "--oracle" in sys.argv:
         from oracle import path_a as A
         t0 = time.perf_counter()
-        s = A.lsq_reconstruct(image, 1.0, 29.0, 4.0, 1, interpolation="nn", **kw)[1]
+        s = A.lsq_reconstruct(image, 1.0, 29.0, 4.0, 1, interpolation="nn", **KW)[1]
         print(f"CPU oracle (NumPy / SciPy restatement), nn: {time.perf_counter() - t0:.1f} s, score {s:.4f}")
 
 
