@@ -10,6 +10,17 @@ from oracle import path_a as A
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["sliced", "general"])
+def product_path(request, monkeypatch):
+    """Both product implementations: slice-major with LDS staging (tilt = psi = 0) and the general gather path
+    (HH_PAB_GENERAL forces it where the sliced one would apply)."""
+    if request.param == "general":
+        monkeypatch.setenv("HH_PAB_GENERAL", "1")
+    else:
+        monkeypatch.delenv("HH_PAB_GENERAL", raising=False)
+    return request.param
+
+
 def _helix_kw(g):
     s2, rs, cs, d2, d3, l2, l3, ov = g["helix_args"]
     return float(s2), float(rs), int(cs), dict(reconstruct_diameter_2d_pixel=int(d2), reconstruct_diameter_3d_pixel=int(d3),
@@ -17,7 +28,7 @@ def _helix_kw(g):
                                                sym_oversample=ov)
 
 
-def test_batch_reproduces_the_reference_scores(golden_dir):
+def test_batch_reproduces_the_reference_scores(golden_dir, product_path):
     """G5's three twists in ONE batch: the reference's scores to 1e-4, the 29-degree volume to the solver's tolerance."""
     g = np.load(golden_dir / "g5_lsq.npz")
     s2, rs, cs, kw = _helix_kw(g)
@@ -54,7 +65,7 @@ def test_batch_composition_and_runs_do_not_change_a_candidate(golden_dir):
     np.testing.assert_array_equal(one[0][0], big[5][0][0])
 
 
-def test_batch_against_the_oracle_with_mixed_candidates(golden_dir):
+def test_batch_against_the_oracle_with_mixed_candidates(golden_dir, product_path):
     """Candidates that differ in twist, rise AND csym, bounded and unbounded, clipped prediction: each equals the oracle's
     lsq_reconstruct (scores 1e-4; the unbounded ones 1e-5, they are a single LSMR solve)."""
     g = np.load(golden_dir / "g5_lsq.npz")
@@ -68,6 +79,20 @@ def test_batch_against_the_oracle_with_mixed_candidates(golden_dir):
             (rec_o, _, _), s_o = A.lsq_reconstruct(img, 1.0, tw, rs, cs, positive_constraint=pc, thresh_fraction=0.0, **kw)
             assert score == pytest.approx(s_o, abs=tol), (pc, tw, rs, cs)
             assert np.abs(maps[0] - rec_o).max() < 1e-2 * max(1e-6, np.abs(rec_o).max()), (pc, tw, rs, cs)
+
+
+def test_batch_with_tilt_psi_dy_against_the_oracle(golden_dir):
+    """Out-of-plane tilt, in-plane rotation and a shift: rays cross slices, so this is the general product path."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    img = g["helix_image"]
+    kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=32,
+              reconstruct_length_3d_pixel=6, tilt_degree=3.0, psi_degree=-2.0, dy_pixel=0.75)
+    cands = [(29.0, 2.0, 1), (30.0, 2.2, 1)]
+    res = lsq_reconstruct_batch(img, 1.0, cands, **kw)
+    for (maps, score), (tw, rs, cs) in zip(res, cands):
+        (rec_o, _, _), s_o = A.lsq_reconstruct(img, 1.0, tw, rs, cs, **kw)
+        assert score == pytest.approx(s_o, abs=1e-4), (tw, rs)
+        assert np.abs(maps[0] - rec_o).max() < 1e-2 * np.abs(rec_o).max()
 
 
 def test_batch_rows_equal_the_single_candidate_problem(golden_dir):
