@@ -125,6 +125,7 @@ EXPORTS = {
     "hh_pab_last_error": (C.c_char_p, [C.c_void_p]),
     "hh_pab_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hh_pab_get_rhs": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.POINTER(C.c_int32)]),
+    "hh_pab_get_pairs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "hh_pab_solve": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_double, C.c_int, C.c_int, _f32p, _f64p,
                                C.POINTER(C.c_int32)]),
     "hh_pab_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),

@@ -197,6 +197,14 @@ class PathABatch:
         self._L.hh_pab_get_rhs(self._h, int(c), b.ctypes.data_as(C.POINTER(C.c_float)), pid.ctypes.data_as(C.POINTER(C.c_int32)))
         return b, pid
 
+    def sym_pairs(self, c):
+        """Symmetry rows of candidate c as voxel-rank pairs, in the reference's row order."""
+        out = np.empty((int(self.m_sym[c]), 2), dtype=np.int32)
+        rc = self._L.hh_pab_get_pairs(self._h, int(c), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc:
+            raise _lib.HeliconHipError(f"hh_pab_get_pairs error {rc}")
+        return out
+
     def solve(self, positive, clip, tol=1e-2, max_iter=200, lsmr_maxiter=1000, want_x=True):
         """``lsq_linear`` + cosine score for every candidate: (x float32 [K, n] or None, scores [K], info [K, 4])."""
         pos = np.ascontiguousarray(np.broadcast_to(np.asarray(positive, dtype=np.int32), (self.count,)))

@@ -308,6 +308,9 @@ const char* hh_pab_last_error(const hh_pab* pab);
 int hh_pab_dims(const hh_pab* pab, int64_t dims[5], int64_t* rows);
 /* b and pixel id (k * D2d + j) of candidate c's data rows (solver:1548-1549) */
 int hh_pab_get_rhs(const hh_pab* pab, int c, float* b, int32_t* b_pid);
+/* the symmetry rows of candidate c as voxel-rank pairs (row: x_i - x_j = 0; build_A_helical_sym_matrix,
+ * solver:1142-1298) in the reference's row order; out: [symmetry rows][2] */
+int hh_pab_get_pairs(hh_pab* pab, int c, int32_t* out);
 /* lsq_linear(A_c, b_c, bounds = positive[c] ? (0, max b_c) : none, tol, max_iter, lsmr_maxiter, lsmr_tol="auto") for
  * every candidate; x -> float32; score = cosine(A_data x [clipped at 0 when clip[c]], b) (solver:484-530).
  * x_out: [count][unknowns] float32 or NULL; scores: [count]; info: [count][4] = {lsq_linear status, trust-region

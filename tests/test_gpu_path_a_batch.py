@@ -125,3 +125,24 @@ def test_batch_rejects_what_it_does_not_do():
         PathABatch(img, [ok, other_box])
     with pytest.raises(NotImplementedError):
         lsq_reconstruct_batch(img, 1.0, [(29.0, 2.0, 1)], fsc_test=1, reconstruct_diameter_3d_pixel=12, reconstruct_length_3d_pixel=4)
+
+
+def test_device_symmetry_pairs_equal_the_sequential_rule(golden_dir, monkeypatch):
+    """build_A_helical_sym_matrix's order-dependent de-duplication (solver:1142-1298), built on the device as "smallest
+    walk index per unordered pair" (hash table + atomicMin), against the host's sequential restatement that the
+    single-candidate hh_pa uses (itself bit-exact against the reference's matrix, fixture G4): same pairs, same order —
+    several pairs of operations, csym 2 and 3, negative twist, half-integer rise, an inner radius, early stop."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    img = np.ascontiguousarray(g["helix_image"], dtype=np.float32)
+    specs = [(29.0, 2.0, 1, 700), (31.0, 2.5, 1, 2000), (58.0, 4.0, 2, 1500), (-29.0, 2.0, 1, 50), (40.0, 1.0, 3, 5000),
+             (27.5, 0.7, 1, 100000)]
+    params = [hh_pa_params(1.0, tw, rs, cs, 0.0, 0.0, 0.0, 20, 32, 20, 4, 6, 700, want, 0, 0, 0) for tw, rs, cs, want in specs]
+    monkeypatch.delenv("HH_PAB_HOST_SYM", raising=False)
+    with PathABatch(img, params) as B:
+        dev = [B.sym_pairs(c) for c in range(len(specs))]
+    monkeypatch.setenv("HH_PAB_HOST_SYM", "1")
+    with PathABatch(img, params) as B:
+        host = [B.sym_pairs(c) for c in range(len(specs))]
+    for d, h, sp in zip(dev, host, specs):
+        assert len(h) > 0
+        np.testing.assert_array_equal(d, h, err_msg=str(sp))
