@@ -442,14 +442,18 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                           thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                           reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
                           reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, return_3d=True, device=0,
-                          batch=256, stats=None):
+                          batch=64, streams=8, stats=None):
     """``lsq_reconstruct`` (solver_linear_regression.py:31-547; nearest-neighbour projector, model "lsq", cosine score)
     for MANY (twist_degree, rise_pixel, csym) candidates of one image: the loop the reference's driver runs as a thread
     pool over ``process_one_task`` (app.py:2473-2476).  ``candidates`` is a sequence of ``(twist, rise, csym)``; the
-    other arguments have the meaning and defaults of ``lsq_reconstruct``.  Up to ``batch`` candidates are set up and
-    solved together on the device (``hh_pab_*``): every LSMR iteration and every trust-region step is one launch for
-    all of them.  Returns ``[((rec3d, half1, half2), score), ...]`` in the order of ``candidates`` (maps are ``None``
-    with ``return_3d=False``).  ``stats``, if a dict, receives launch / synchronisation counters."""
+    other arguments have the meaning and defaults of ``lsq_reconstruct``.
+
+    Up to ``batch`` candidates form one device-resident group (``hh_pab_*``): every LSMR iteration and every
+    trust-region step is one launch for the whole group, whose candidates wait for each other at the trust-region
+    steps.  Up to ``streams`` groups run at once, each from its own host thread on its own HIP stream, so one group's
+    stragglers overlap with the other groups' full launches.  A candidate's result does not depend on how the list is
+    cut.  Returns ``[((rec3d, half1, half2), score), ...]`` in the order of ``candidates`` (maps are ``None`` with
+    ``return_3d=False``).  ``stats``, if a dict, receives launch / synchronisation counters."""
     img = np.asarray(projection_image)
     cands = [(float(t), float(r), int(c)) for t, r, c in candidates]
     if fsc_test == 1:
@@ -459,10 +463,13 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                                             reconstruct_diameter_3d_inner_pixel, sym_oversample)
     halves = (0, 1, 2) if fsc_test and fsc_test > 1 else (0,)
     per = len(halves)
-    out = []
     step = max(1, int(batch) // per)
-    for lo in range(0, len(cands), step):
-        chunk = cands[lo: lo + step]
+    # groups of equal size (the last ones one shorter) rather than full groups and a remainder
+    n_groups = max(1, -(-len(cands) // step))
+    bounds = [round(k * len(cands) / n_groups) for k in range(n_groups + 1)]
+
+    def run_group(g):
+        chunk = cands[bounds[g]: bounds[g + 1]]
         params, positive = [], []
         for tw, rs, cs in chunk:
             pitch_pixel = round(rs * 360 / abs(tw))
@@ -477,12 +484,8 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                 raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
                                  "the 3-D diameter): the reference's two masks would rank the voxels differently")
             x, scores, info = B.solve(positive, 1 if thresh_fraction >= 0 else 0, want_x=return_3d)
-            if stats is not None:
-                c = B.counters()
-                for k, v in c.items():
-                    stats[k] = stats.get(k, 0) + v
-                stats["device_bytes"] = max(stats.get("device_bytes", 0), B.device_bytes)
-                stats.setdefault("info", []).extend(info.tolist())
+            counters = dict(B.counters(), device_bytes=B.device_bytes, info=info.tolist())
+        res = []
         for k in range(len(chunk)):
             sc = scores[k * per: (k + 1) * per]
             score = float(sc[0] / 2 + (sc[1] + sc[2]) / 4 if per == 3 else sc[0])                          # solver:526-529
@@ -492,7 +495,26 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                     rec = np.zeros(mask.shape, dtype=np.float32)
                     rec[mask] = x[k * per + h]
                     maps[h] = rec
-            out.append(((maps[0], maps[1], maps[2]), score))
+            res.append(((maps[0], maps[1], maps[2]), score))
+        return res, counters
+
+    if n_groups == 1 or streams <= 1:
+        done = [run_group(g) for g in range(n_groups)]
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(int(streams), n_groups)) as pool:
+            done = list(pool.map(run_group, range(n_groups)))
+    out = []
+    for res, counters in done:
+        out.extend(res)
+        if stats is not None:
+            for k in ("launches", "host_syncs", "lsmr_iterations_queued"):
+                stats[k] = stats.get(k, 0) + counters[k]
+            stats["device_bytes"] = stats.get("device_bytes", 0) + counters["device_bytes"]
+            stats.setdefault("info", []).extend(counters["info"])
+    if stats is not None:
+        stats["groups"] = n_groups
     return out
 
 

@@ -82,6 +82,16 @@ def main():
     res = lsq_reconstruct_batch(image, 1.0, [(t, 4.0, 1) for t in np.linspace(27, 31, 100)], return_3d=True, **KW)
     print(f"lsq_reconstruct_batch, 100 candidates with their maps: {time.perf_counter() - t0:.3f} s; best "
           f"{np.linspace(27, 31, 100)[int(np.argmax([s for _, s in res]))]:.3f}", flush=True)
+    # the whole thing as a user calls it: groups of `batch` candidates on `streams` concurrent HIP streams
+    for total, batch, streams in ((1024, 256, 1), (1024, 128, 4), (1024, 64, 8), (1024, 64, 16), (1024, 32, 16), (2048, 128, 8)):
+        tw = np.linspace(27.0, 31.0, total)
+        st = {}
+        t0 = time.perf_counter()
+        res = lsq_reconstruct_batch(image, 1.0, [(t, 4.0, 1) for t in tw], return_3d=False, batch=batch, streams=streams, stats=st, **KW)
+        dt = time.perf_counter() - t0
+        print(f"lsq_reconstruct_batch: {total} candidates, groups of {batch} on {streams} stream(s): {dt:.3f} s = {total / dt:.1f} "
+              f"candidates/s (set-up included); {st['launches']} launches, {st['host_syncs']} host syncs; best "
+              f"{tw[int(np.argmax([s for _, s in res]))]:.3f}", flush=True)
     if "--oracle" in sys.argv:
         from oracle import path_a as A
         t0 = time.perf_counter()
