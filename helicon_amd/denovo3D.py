@@ -657,27 +657,10 @@ def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_d
     return data
 
 
-def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
-              target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
-              reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device, transpose,
-              low_pass):
-    """pipeline.py:242-496 with target_apix2d = apix2d_orig (no rescale): the reconstruction box from the tube's
-    dimensions, ``lsq_reconstruct``, helical symmetrisation back on the input's grid, projections and z sections."""
-    from .solver import lsq_reconstruct
-
-    # the image the reference would have at pipeline.py:286 (``prepared`` already went through the low pass, the
-    # transpose and, with thresh_fraction >= 0, the background subtraction + threshold + / max), and its ``data_orig``
-    img = np.asarray(prepared)
-    ny, nx = img.shape
-    if thresh_fraction is not None and thresh_fraction >= 0:
-        # data_orig is the image after the in-place median subtraction (pipeline.py:277-282: ``data_orig = data`` aliases it)
-        base = _prepare_task_image(data, apix, low_pass, transpose, None, tube_diameter, device)
-        rec_d0 = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
-        nr = min(ny // 2 - 1, int(np.ceil(rec_d0 / 2 / apix) + 1))
-        data_orig = np.asarray(base) - np.median(np.asarray(base)[(ny // 2 - nr, ny // 2 + nr), :])
-        data_orig = data_orig.astype(np.asarray(base).dtype, copy=False)
-    else:
-        data_orig = img
+def lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_length, tube_diameter, tube_diameter_inner,
+            reconstruct_length, sym_oversample, return_3d):
+    """The reconstruction box of one task — pipeline.py:242-349 with target_apix2d = apix2d_orig (no rescale), the
+    reference's integer arithmetic: ``(apix3d, D2d, L2d, D3d, D3d_inner, L3d, sym_oversample)``."""
     a2 = apix
     # tube length, reconstruction diameter / length (pipeline.py:242-266)
     if tube_length < 0:
@@ -716,6 +699,34 @@ def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, cs
             sym_oversample = max(1, int(round(ratio / 100)) * 100)
         if return_3d:
             sym_oversample *= 2
+    return a3, d2, l2, d3, d3_inner, l3, sym_oversample
+
+
+def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
+              target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
+              reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device, transpose,
+              low_pass):
+    """pipeline.py:242-496 with target_apix2d = apix2d_orig (no rescale): the reconstruction box from the tube's
+    dimensions, ``lsq_reconstruct``, helical symmetrisation back on the input's grid, projections and z sections."""
+    from .solver import lsq_reconstruct
+
+    # the image the reference would have at pipeline.py:286 (``prepared`` already went through the low pass, the
+    # transpose and, with thresh_fraction >= 0, the background subtraction + threshold + / max), and its ``data_orig``
+    img = np.asarray(prepared)
+    ny, nx = img.shape
+    if thresh_fraction is not None and thresh_fraction >= 0:
+        # data_orig is the image after the in-place median subtraction (pipeline.py:277-282: ``data_orig = data`` aliases it)
+        base = _prepare_task_image(data, apix, low_pass, transpose, None, tube_diameter, device)
+        rec_d0 = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
+        nr = min(ny // 2 - 1, int(np.ceil(rec_d0 / 2 / apix) + 1))
+        data_orig = np.asarray(base) - np.median(np.asarray(base)[(ny // 2 - nr, ny // 2 + nr), :])
+        data_orig = data_orig.astype(np.asarray(base).dtype, copy=False)
+    else:
+        data_orig = img
+    a2 = apix
+    a3, d2, l2, d3, d3_inner, l3, sym_oversample = lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_length,
+                                                          tube_diameter, tube_diameter_inner, reconstruct_length, sym_oversample,
+                                                          return_3d)
     model = {k: v for k, v in opts.items() if k in ("model",)} or {"model": "lsq"}
     (rec3d, set1, set2), score = lsq_reconstruct(
         img, a2 / a3, twist, rise / a3, csym, tilt, psi, dy / a2, thresh_fraction=thresh_fraction,

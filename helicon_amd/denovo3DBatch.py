@@ -50,7 +50,9 @@ def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
     parser.add_argument("--out", default=None, help=".npz with scores[S, C, T, R], twists, rises, csyms")
     parser.add_argument("--rescore", type=int, default=0, help="re-score this many best candidates per image with the least-squares scorer")
     parser.add_argument("--tube-diameter", type=float, default=None, help="Angstrom, for --rescore (default 0.8 * ny * apix)")
-    parser.add_argument("--interpolation", choices=("nn", "linear"), default="linear", help="for --rescore (the app's default: linear)")
+    parser.add_argument("--interpolation", choices=("nn", "linear"), default="nn",
+                        help="for --rescore: nn = all candidates set up and solved together on the device; linear (the "
+                             "reference app's default) = one call per candidate from a thread pool")
     parser.add_argument("--threads", type=int, default=8, help="for --rescore")
     parser.add_argument("--map-out", default=None, help="for --rescore: write the best candidate's helically symmetrised map of every "
                         "image to <map-out>_<image>.mrc (the app's map download, app.py:1267-1287)")
@@ -105,13 +107,42 @@ def run(args) -> dict:
 
 
 def rescore(image, candidates, args) -> list:
-    """The least-squares scorer on a list of sweep candidates (dicts with twist, rise, csym, score), best first."""
+    """The least-squares scorer on a list of sweep candidates (dicts with twist, rise, csym, score), best first.
+
+    With the nearest-neighbour projector the candidates go through ``lsq_reconstruct_batch``: they are grouped by
+    reconstruction box (the reference derives the box length from the candidate's rise, pipeline.py:259-266, 319-331) and
+    every group is set up and solved on the device at once — scores only, the display products of ``process_one_task``
+    (symmetrised map, projections) are made for the one map ``--map-out`` asks for.  With trilinear interpolation every
+    candidate is one ``process_one_task`` call from a thread pool, like the reference's driver (app.py:2473-2476)."""
+    ny, nx = image.shape
+    tube_d = args.tube_diameter if args.tube_diameter is not None else 0.8 * ny * args.apix
+    if args.interpolation == "nn":
+        from .denovo3D import _prepare_task_image, lsq_box
+        from .solver import lsq_reconstruct_batch
+
+        if not np.std(image):   # pipeline.py:214-218
+            return [dict(twist=c["twist"], rise=c["rise"], csym=c["csym"], sweep_score=c["score"], lsq_score=None) for c in candidates]
+        img = np.asarray(_prepare_task_image(image, args.apix, 0, 0, None, tube_d, args.device))
+        groups = {}
+        for k, c in enumerate(candidates):
+            box = lsq_box(ny, nx, args.apix, c["rise"], (c["rise"], c["rise"]), (0, 0), args.apix, -1, tube_d, 0, -1, 1, 0)
+            groups.setdefault(box, []).append(k)
+        scores = [None] * len(candidates)
+        for (a3, d2, l2, d3, d3_inner, l3, oversample), members in groups.items():
+            res = lsq_reconstruct_batch(img, args.apix / a3, [(candidates[k]["twist"], candidates[k]["rise"] / a3, candidates[k]["csym"])
+                                                             for k in members],
+                                        reconstruct_diameter_3d_inner_pixel=d3_inner, reconstruct_diameter_2d_pixel=d2,
+                                        reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2, reconstruct_length_3d_pixel=l3,
+                                        sym_oversample=oversample, return_3d=False, device=args.device, streams=max(1, args.threads))
+            for k, (_, sc) in zip(members, res):
+                scores[k] = sc
+        got = [dict(twist=c["twist"], rise=c["rise"], csym=c["csym"], sweep_score=c["score"], lsq_score=float(scores[k]))
+               for k, c in enumerate(candidates)]
+        return sorted(got, key=lambda r: -r["lsq_score"])
+
     from concurrent.futures import ThreadPoolExecutor
 
     from .denovo3D import process_one_task
-
-    ny = image.shape[0]
-    tube_d = args.tube_diameter if args.tube_diameter is not None else 0.8 * ny * args.apix
 
     def one(c):
         # the 36 positional arguments of pipeline.py:84-121 (no rescale: target_apix2d = apix; voxel size = pixel size)

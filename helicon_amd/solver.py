@@ -464,8 +464,9 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     halves = (0, 1, 2) if fsc_test and fsc_test > 1 else (0,)
     per = len(halves)
     step = max(1, int(batch) // per)
-    # groups of equal size (the last ones one shorter) rather than full groups and a remainder
-    n_groups = max(1, -(-len(cands) // step))
+    # groups of equal size rather than full groups and a remainder; a short list is still spread over the streams (a
+    # group of a dozen candidates already fills its launches' latency)
+    n_groups = max(1, -(-len(cands) // step), min(int(streams), len(cands) // 12))
     bounds = [round(k * len(cands) / n_groups) for k in range(n_groups + 1)]
 
     def run_group(g):
