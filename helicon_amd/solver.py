@@ -206,12 +206,12 @@ class PathABatch:
         return out
 
     def solve(self, positive, clip, tol=1e-2, max_iter=200, lsmr_maxiter=1000, want_x=True):
-        """``lsq_linear`` + cosine score for every candidate: (x float32 [K, n] or None, scores [K], info [K, 4])."""
+        """``lsq_linear`` + cosine score for every candidate: (x float32 [K, n] or None, scores [K], info [K, 5])."""
         pos = np.ascontiguousarray(np.broadcast_to(np.asarray(positive, dtype=np.int32), (self.count,)))
         clp = np.ascontiguousarray(np.broadcast_to(np.asarray(clip, dtype=np.int32), (self.count,)))
         x = np.empty((self.count, self.n), dtype=np.float32) if want_x else None
         scores = np.empty(self.count, dtype=np.float64)
-        info = np.empty((self.count, 4), dtype=np.int32)
+        info = np.empty((self.count, 5), dtype=np.int32)
         i32 = C.POINTER(C.c_int32)
         rc = self._L.hh_pab_solve(self._h, pos.ctypes.data_as(i32), clp.ctypes.data_as(i32), float(tol), int(max_iter),
                                   int(lsmr_maxiter), None if x is None else x.ctypes.data_as(C.POINTER(C.c_float)),

@@ -313,8 +313,8 @@ int hh_pab_get_rhs(const hh_pab* pab, int c, float* b, int32_t* b_pid);
 int hh_pab_get_pairs(hh_pab* pab, int c, int32_t* out);
 /* lsq_linear(A_c, b_c, bounds = positive[c] ? (0, max b_c) : none, tol, max_iter, lsmr_maxiter, lsmr_tol="auto") for
  * every candidate; x -> float32; score = cosine(A_data x [clipped at 0 when clip[c]], b) (solver:484-530).
- * x_out: [count][unknowns] float32 or NULL; scores: [count]; info: [count][4] = {lsq_linear status, trust-region
- * iterations, LSMR solves, LSMR iterations} or NULL. */
+ * x_out: [count][unknowns] float32 or NULL; scores: [count]; info: [count][5] = {lsq_linear status, trust-region
+ * iterations, LSMR solves, LSMR iterations, of which in the first (unconstrained) solve} or NULL. */
 int hh_pab_solve(hh_pab* pab, const int32_t* positive, const int32_t* clip, double tol, int max_iter, int lsmr_maxiter,
                  float* x_out, double* scores, int32_t* info);
 /* counters of the last hh_pab_solve: {kernel launches, host synchronisations, LSMR iterations queued} */

@@ -45,12 +45,20 @@ def batch_run(image, k, repeat=2):
                    device_bytes=B.device_bytes, lsmr_iterations=int(info[:, 3].sum()), lsmr_solves=int(info[:, 2].sum()),
                    outer_iterations=int(info[:, 1].sum()), best_twist=float(twists[int(np.argmax(scores))]),
                    best_score=float(scores.max()), **cnt)
-        # bytes a product pair (A x, A^T y) moves per candidate: the compact map + the transposed lists + the pairs, once each
-        nnz = float(np.mean(B.m_data)) * NY
-        run["bytes_per_product_pair"] = nnz * 4 + (nnz + 2 * float(np.mean(B.m_sym))) * 4 + float(np.mean(B.m_sym)) * 8
-        # one LSMR iteration also streams its vectors: u (read + write), v (r + w), h, hbar, x (r + w each), v again
-        m = float(np.mean(B.m_data + B.m_sym))
-        run["bytes_per_lsmr_iteration"] = run["bytes_per_product_pair"] + 8 * (2 * m + 9 * B.n)
+        # Algorithmic bytes of ONE LSMR iteration of one candidate (Path A): every array an iteration must touch,
+        # once per kernel that needs it — the uint16 map (padded rows) in both products, the symmetry pairs (A x) and their
+        # transposed lists (A^T y), u read + written (A x) and read (A^T y), v read twice and written once, h / hbar / x read
+        # and written; with the trust-region step's operator [A diag(d); diag(root)] also d (both products), root (both)
+        # and the n extra entries of u.
+        n, md, ms = float(B.n), float(np.mean(B.m_data)), float(np.mean(B.m_sym))
+        mp = 2 * md * ((NY + 63) // 64 * 64) * 2
+        plain = mp + 16 * ms + 4 * n + 8 * (3 * (md + ms) + 9 * n)
+        aug = mp + 16 * ms + 4 * n + 8 * (3 * (md + ms) + 16 * n)
+        first = int(info[:, 4].sum())
+        run["bytes_per_lsmr_iteration_plain"] = plain
+        run["bytes_per_lsmr_iteration_augmented"] = aug
+        run["first_solve_iterations"] = first
+        run["bytes_per_lsmr_iteration"] = (plain * first + aug * (run["lsmr_iterations"] - first)) / max(1, run["lsmr_iterations"])
         B.close()
         if best is None or run["total_s"] < best["total_s"]:
             best = run
