@@ -222,9 +222,10 @@ class PathABatch:
         return x, scores, info
 
     def counters(self):
-        out = (C.c_int64 * 3)()
+        out = (C.c_int64 * 4)()
         self._L.hh_pab_counters(self._h, out)
-        return {"launches": int(out[0]), "host_syncs": int(out[1]), "lsmr_iterations_queued": int(out[2])}
+        return {"launches": int(out[0]), "host_syncs": int(out[1]), "lsmr_iterations_queued": int(out[2]),
+                "self_check_failures": int(out[3])}
 
 
 # ---- scipy.optimize.lsq_linear(method="trf", lsq_solver="lsmr", lsmr_tol="auto") around the device operator ----------

@@ -317,8 +317,9 @@ int hh_pab_get_pairs(hh_pab* pab, int c, int32_t* out);
  * iterations, LSMR solves, LSMR iterations, of which in the first (unconstrained) solve} or NULL. */
 int hh_pab_solve(hh_pab* pab, const int32_t* positive, const int32_t* clip, double tol, int max_iter, int lsmr_maxiter,
                  float* x_out, double* scores, int32_t* info);
-/* counters of the last hh_pab_solve: {kernel launches, host synchronisations, LSMR iterations queued} */
-int hh_pab_counters(const hh_pab* pab, int64_t out[3]);
+/* counters of the last hh_pab_solve: {kernel launches, host synchronisations, LSMR iterations queued, failures of the
+ * solver's self-check (every workgroup of a launch saw the per-candidate state the previous launch wrote; must be 0)} */
+int hh_pab_counters(const hh_pab* pab, int64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,10 @@ from helicon_amd.solver import PathABatch, hh_pa_params, lsq_reconstruct, lsq_re
 NY, NX, L3 = 64, 128, 16
 KW = dict(reconstruct_diameter_2d_pixel=NY, reconstruct_diameter_3d_pixel=NY, reconstruct_length_2d_pixel=NX,
           reconstruct_length_3d_pixel=L3)
+# the reference's row target min(2**26, max(D2d * L2d, unknowns) * sym_oversample) (solver:148-150, 168-170) for this box
+# with sym_oversample = 1: 47,952 voxels in the cylinder (round 2's tool, and this one until the profile of this round,
+# passed D2d * L2d = 8,192 here: a six times smaller data block than lsq_reconstruct builds)
+TARGET = 47952
 
 
 def test_image():
@@ -32,8 +36,7 @@ def batch_run(image, k, repeat=2):
     cands = [(float(t), 4.0, 1) for t in twists]
     best = None
     for _ in range(repeat):
-        target = NY * NX   # = max(d2 * l2, unknowns) here
-        params = [hh_pa_params(1.0, t, r, c, 0.0, 0.0, 0.0, NY, NX, NY, 0, L3, target, target, 0, 0, 0) for t, r, c in cands]
+        params = [hh_pa_params(1.0, t, r, c, 0.0, 0.0, 0.0, NY, NX, NY, 0, L3, TARGET, TARGET, 0, 0, 0) for t, r, c in cands]
         t0 = time.perf_counter()
         B = PathABatch(image, params)
         t1 = time.perf_counter()
