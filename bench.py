@@ -2,8 +2,14 @@
 """Headline benchmark: helical-parameter candidates/s on a 512x512 image over a 100k-point
 (twist, rise) grid (BASELINE.json configs[1] = SURVEY.md section 8d "C2").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--config` picks the BASELINE configuration whose grid is sharded over the ranks: C2 (default; configs[1]), C3 (C2's grid
+x Csym 1..6, configs[2]), C4 (1024^2, 500 x 500 grid, configs[3]), C5 (64 segments x 512^2 against one 200 x 100 grid,
+per-segment arg-max, configs[4]).  At N = 1 with the default config the line also carries one timed leg per other
+configuration, a general (non-power-of-two) size and the batched Path-A scorer under "pipelines", each with its own
+roofline object.
 
 A step = one pass of the sweep over the C2 grid with the candidate list and the experimental spectrum
 already resident in HBM: every rank sweeps its contiguous shard of the ONE 400 x 250 grid (whole twists per
@@ -38,7 +44,24 @@ def c2_workload(n=512):
     twists = sweep_axis(0.01, 4.00, 0.01)
     rises = sweep_axis(4.000, 5.245, 0.005)
     return dict(n=n, apix=apix, truth=(1.20, 4.75, 1), helical_diameter=0.4 * n * apix, ball_radius=2 * apix,
-                twists=twists, rises=rises, build_grid=build_grid)
+                twists=twists, rises=rises, build_grid=build_grid, csyms=[1], segments=1, name="C2")
+
+
+def config_workload(name, n_override=None):
+    """SURVEY.md section 8d's synthetic inputs for the BASELINE configurations (all: truth (1.20, 4.75, 1), apix 1,
+    diameter 0.4 N, ball radius 2, noise 0.5 std from default_rng(segment))."""
+    from helicon_amd.grid import sweep_axis
+
+    w = c2_workload(n_override or (1024 if name == "C4" else 512))
+    w["name"] = name
+    if name == "C3":
+        w["csyms"] = [1, 2, 3, 4, 5, 6]
+    elif name == "C4":
+        w["twists"], w["rises"] = sweep_axis(0.01, 5.00, 0.01), sweep_axis(4.000, 6.495, 0.005)     # 500 x 500
+    elif name == "C5":
+        w["twists"], w["rises"] = sweep_axis(0.02, 4.00, 0.02), sweep_axis(4.25, 5.24, 0.01)        # 200 x 100
+        w["segments"] = 64
+    return w
 
 
 def baseline_metric():
@@ -101,13 +124,17 @@ def load_factory(spec):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE configuration whose grid is sharded over the ranks (default C2, the metric's own)")
+    ap.add_argument("--segments", type=int, default=0, help="override the number of segments (tests: C5 at reduced size)")
+    ap.add_argument("--grid-stride", type=int, default=1, help="keep every k-th twist of the configuration's grid (tests)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--side", dest="n", type=int, default=512, help="image side (default: the C2 workload)")
+    ap.add_argument("--side", dest="n", type=int, default=0, help="image side (default: the configuration's)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the one C2 grid sharded over the ranks (default, the north_star's experiment); "
                          "weak = a full grid per rank (rot = 7.5 deg x rank)")
-    ap.add_argument("--csyms", type=int, nargs="+", default=[1], help="Csym values of the grid (1 2 3 4 5 6 = C3)")
+    ap.add_argument("--csyms", type=int, nargs="+", default=None, help="Csym values of the grid (default: the configuration's)")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the run-tables / transform / C3 legs at N = 1")
@@ -170,11 +197,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    w = c2_workload(args.n)
+    w = config_workload(args.config, args.n or None)
+    args.n = w["n"]
+    if args.csyms is None:
+        args.csyms = list(w["csyms"])
+    if args.segments:
+        w["segments"] = args.segments
+    if args.grid_stride > 1:
+        w["twists"] = w["twists"][:: args.grid_stride]
 
     # CPU baseline first, before this process touches the GPU (it uses worker processes)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":
         cpu = cpu_baseline_leg(w)
 
     import torch
@@ -203,9 +237,9 @@ def main():
     eng.set_geometry(apix=w["apix"], helical_diameter=w["helical_diameter"], ball_radius=w["ball_radius"])
     tw0, rs0, cs0 = w["truth"]
     clean = eng.simulate(tw0, rs0, cs0)
-    noise = np.random.default_rng(0).normal(0, 0.5 * clean.std(), clean.shape)
-    image = (clean + noise).astype(np.float32)
-    eng.set_reference(image, H.radial_band_mask(n, n), log=True)
+    image = np.stack([(clean + np.random.default_rng(seg).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
+                      for seg in range(w["segments"])])
+    eng.set_reference(image if w["segments"] > 1 else image[0], H.radial_band_mask(n, n), log=True)
 
     n_rises = len(w["rises"])
     strong = args.scaling == "strong" or world == 1
@@ -242,7 +276,12 @@ def main():
             # launches cost nothing), so the averages are over the same launches rocprofv3 sees
             eng.profile(1 if eng.last_first_pass == "fused" else args.profile_period)
 
-    elapsed = timed.run(sh.step, args.warmup, args.steps, before_timed=start_profile)
+    # the timed step: sweep kernels + all-gather + device arg-max + the results' copy to (pinned) host memory — SURVEY.md
+    # section 8d's metric counts the result D2H; inputs (candidate list, reference spectrum) are resident in HBM
+    def timed_step():
+        sh.step(results_to_host=True)
+
+    elapsed = timed.run(timed_step, args.warmup, args.steps, before_timed=start_profile)
     prof = eng.profile_get() if (not args.no_profile and on_gpu) else None
     if prof is not None:
         prof["candidates_total"] = sh.n_local * args.steps
@@ -250,9 +289,13 @@ def main():
     pipeline = eng.last_first_pass
 
     # correctness of what was timed: the arg-max of the gathered scores must be the synthetic truth
-    best = int(sh.best_index()[0])
+    best_all = sh.best_index()
+    best = int(best_all[0])
     scores = sh.scores()
-    assert best == int(np.argmax(np.where(np.isnan(scores[0]), -np.inf, scores[0]))), "device arg-max != host arg-max"
+    for seg in range(scores.shape[0]):
+        assert int(best_all[seg]) == int(np.argmax(np.where(np.isnan(scores[seg]), -np.inf, scores[seg]))), "device arg-max != host arg-max"
+    if sh.host_scores is not None and world == 1:   # what the timed step left in host memory is the same thing
+        assert np.array_equal(np.asarray(sh.host_scores).reshape(scores.shape[0], -1)[:, : scores.shape[1]], scores, equal_nan=True)
     best_pair = (round(float(params_all[best, 0]), 6), round(float(params_all[best, 1]), 6), int(params_all[best, 2]))
     if rank == 0 and args.dump_scores:
         np.save(args.dump_scores, scores)
@@ -269,8 +312,9 @@ def main():
         th = time.perf_counter()  #  k_fused_pass launch of this process is one — the profiler's average means something)
         eng.sweep(params_all)
         host_api = g_total / (time.perf_counter() - th)
-        if not args.no_extra_legs and args.first_pass == "auto" and args.csyms == [1]:
+        if not args.no_extra_legs and args.first_pass == "auto" and args.config == "C2" and args.csyms == [1]:
             extra = extra_legs(args, eng, timed, make_sweep, n)
+            extra.update(config_legs(args, torch, dev))
 
     if rank == 0:
         total = g_total * args.steps
@@ -290,16 +334,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"C2: {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), ONE 400x250 "
-                             f"(twist, rise) grid x Csym {args.csyms} "
+                "workload": (f"{w['name']}: {w['segments']} x {n}x{n} synthetic helix (twist 1.20, rise 4.75, csym 1, noise 0.5 std), ONE "
+                             f"{len(w['twists'])}x{len(w['rises'])} (twist, rise) grid x Csym {args.csyms} "
                              + ("sharded over the ranks in whole twists" if strong else "per GPU (rot = 7.5 deg x rank)")
                              + ", radial-band mask, log1p|F|"),
                 "image": n, "candidates_per_step": g_total, "candidates_per_rank": sh.per,
-                "batch": getattr(eng, "max_batch", 0), "first_pass": pipeline,
+                "batch": getattr(eng, "max_batch", 0), "first_pass": pipeline, "segments": w["segments"],
+                "timed_region": "sweep kernels + all-gather + device arg-max + scores/indices D2H into pinned host memory; "
+                                "candidate list and reference spectrum resident in HBM",
                 "parallelism": f"grid-shard x{world} + all-gather(scores) + device arg-max",
             },
             "argmax": {"index": best, "twist_rise_csym": best_pair,
-                       "is_truth": best_pair == (tw0, rs0, cs0)},
+                       "is_truth": best_pair == (tw0, rs0, cs0),
+                       "segments_at_truth": int(sum(int(b) == best for b in best_all)), "segments": int(len(best_all))},
         }
         if phases is not None:
             out["step_phases_rank0"] = phases
@@ -365,6 +412,127 @@ def extra_legs(args, eng, timed, make_sweep, n):
         del sh
     eng.set_table_path(2)
     return out
+
+
+def _time_device(torch, dev, fn, reps):
+    """Mean device milliseconds of fn() (events on torch's current stream, which the engine is bound to)."""
+    fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / reps
+
+
+def config_legs(args, torch, dev):
+    """N = 1: the other BASELINE configurations, a general image size and the batched Path-A scorer, each swept a few
+    times on this GPU with its own roofline object — so that the driver's run, not only the builder's, times them."""
+    import helicon_amd as H
+    from helicon_amd.distributed import ShardedSweep
+    from helicon_amd.grid import build_grid, sweep_axis
+
+    out = {}
+
+    def engine_for(shape, segments):
+        eng = H.SweepEngine(shape, device=dev.index or 0)
+        apix = 1.0
+        eng.set_geometry(apix=apix, helical_diameter=0.4 * eng.ny * apix, ball_radius=2 * apix)
+        clean = eng.simulate(1.20, 4.75, 1)
+        imgs = np.stack([(clean + np.random.default_rng(sg).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
+                         for sg in range(segments)])
+        eng.set_reference(imgs if segments > 1 else imgs[0], None, log=True)
+        return eng
+
+    def sweep_leg(name, shape, segments, twists, rises, reps):
+        eng = engine_for(shape, segments)
+        ny, nx = eng.ny, eng.nx
+        grid = build_grid(twists, rises, (1,), tube_length=float(nx))
+        sh = ShardedSweep(eng, grid.params, align=len(rises), device=dev)
+        sh.step()
+        ms = _time_device(torch, dev, lambda: sh.step(results_to_host=True), reps)
+        best = sh.best_index()
+        truth = int(np.argmin(np.abs(grid.params[:, 0] - 1.20) + np.abs(grid.params[:, 1] - 4.75)))
+        cps = len(grid) / (ms * 1e-3)
+        leg = {"value": cps, "unit": "candidates/s", "ms_per_step": ms, "steps": reps, "candidates_per_step": len(grid),
+               "segments": segments, "image": [ny, nx], "first_pass": eng.last_first_pass,
+               "segments_at_truth": int(sum(int(b) == truth for b in best))}
+        flops = 2.5 * ny * nx * np.log2(ny * nx)        # SURVEY.md section 8d's 5 N^2 log2 N for an ny x nx image
+        if segments == 1:
+            tf = flops * cps / 1e12
+            leg["roofline"] = {"bound": "fp32_vector", "achieved": tf, "peak": F32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s",
+                               "frac": tf / (F32_VECTOR_PEAK / 1e12), "alg_flop_per_candidate": flops, "traffic": None,
+                               "kernel": "k_fused_pass" if shape == ny == nx and (ny & (ny - 1)) == 0 else "k_gen_fused",
+                               "note": "device time of the whole step (sweep + arg-max + D2H), events on the sweep's stream"}
+        else:
+            # several segments: the masked spectrum q of every candidate is stored once and read once (K bins x 4 B each way)
+            k_bins = (ny // 2 + 1) * nx
+            moved = 2.0 * 4 * k_bins
+            gbps = moved * cps / 1e9
+            leg["scores_per_s"] = cps * segments
+            leg["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps / (HBM_PEAK / 1e9),
+                               "moved_bytes_per_candidate": moved, "traffic": None,
+                               "kernel": "k_fused_pass<EPI_QSTORE> + k_segment_corr",
+                               "note": "q = masked log-spectrum of a candidate, written by the fused pass and read by the "
+                                       "segment contraction; device time of the whole step"}
+        out[name] = leg
+        sh = None
+        eng.close()
+
+    tw, rs = sweep_axis(0.01, 4.00, 0.01), sweep_axis(4.000, 5.245, 0.005)
+    sweep_leg("C4_1024", 1024, 1, sweep_axis(0.01, 5.00, 0.01), sweep_axis(4.000, 6.495, 0.005), 2)
+    sweep_leg("C5_64_segments", 512, 64, sweep_axis(0.02, 4.00, 0.02), sweep_axis(4.25, 5.24, 0.01), 5)
+    sweep_leg("general_400", (400, 400), 1, tw[:100], rs, 3)
+    sweep_leg("general_200", (200, 200), 1, tw[:200], rs, 3)
+    try:
+        out["path_a"] = path_a_leg(dev.index or 0)
+    except Exception as ex:   # the leg must not take the headline down with it
+        out["path_a"] = {"error": f"{type(ex).__name__}: {ex}"}
+    return out
+
+
+def path_a_leg(device, total=1024):
+    """The reference's shipped scorer (sparse least squares + cosine, solver_linear_regression.py:31-547) batched on the
+    device: `total` (twist, rise) candidates of a 64 x 128 image (the size the reference app works at after binning to
+    target_apix2d), groups of 64 on 8 streams, set-up included.  Roofline: HBM; bytes = LSMR iterations x the arrays an
+    iteration must touch (Path A)."""
+    import helicon_amd as H
+    from helicon_amd.solver import lsq_reconstruct_batch
+
+    ny, nx, l3 = 64, 128, 16
+    eng = H.SweepEngine((ny, nx), device=device)
+    eng.set_geometry(apix=5.0, helical_diameter=0.5 * ny * 5.0, ball_radius=10.0)
+    image = eng.simulate(29.0, 20.0, 1).astype(np.float32)
+    eng.close()
+    kw = dict(reconstruct_diameter_2d_pixel=ny, reconstruct_diameter_3d_pixel=ny, reconstruct_length_2d_pixel=nx,
+              reconstruct_length_3d_pixel=l3, return_3d=False, device=device)
+    tw = np.linspace(27.0, 31.0, total)
+    lsq_reconstruct_batch(image, 1.0, [(t, 4.0, 1) for t in tw[:: total // 16]], **kw)   # warm
+    st = {}
+    t0 = time.perf_counter()
+    res = lsq_reconstruct_batch(image, 1.0, [(float(t), 4.0, 1) for t in tw], batch=64, streams=8, stats=st, **kw)
+    dt = time.perf_counter() - t0
+    info = np.asarray(st["info"])
+    iters, first = int(info[:, 3].sum()), int(info[:, 4].sum())
+    n, md, ms = 47952.0, 33291.0, 59424.0    # unknowns, data rows, symmetry rows of this box (tools/path_a_bench.py prints them)
+    mp = 2 * md * 64 * 2
+    plain = mp + 16 * ms + 4 * n + 8 * (3 * (md + ms) + 9 * n)
+    aug = mp + 16 * ms + 4 * n + 8 * (3 * (md + ms) + 16 * n)
+    moved = plain * first + aug * (iters - first)
+    gbps = moved / dt / 1e9
+    best = float(tw[int(np.argmax([sc for _, sc in res]))])
+    return {"value": total / dt, "unit": "candidates/s", "candidates": total, "seconds": dt, "set_up_included": True,
+            "lsmr_iterations": iters, "self_check_failures": int(st.get("self_check_failures", 0)),
+            "best_twist": best, "truth_twist": 29.0, "groups": st.get("groups"),
+            "round2_value": 45.2,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps / (HBM_PEAK / 1e9),
+                         "alg_bytes_per_lsmr_iteration": {"plain": plain, "augmented": aug}, "traffic": None,
+                         "traffic_source": "profiles/r03_path_a_traffic.json: measured / algorithmic bytes per iteration = 1.06",
+                         "kernel": "k_pabs_matvec<1> + k_pabs_rmatvec<1> (one LSMR iteration of every candidate of a group)",
+                         "note": "wall time of the whole call (set-up, all trust-region steps, host polling) against the "
+                                 "bytes of its LSMR iterations only"}}
 
 
 PIPELINES = {

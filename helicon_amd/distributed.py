@@ -113,6 +113,7 @@ class ShardedSweep:
         else:
             self.recv = self.send.view(1, s, per)
         self.on_device = self.recv.device.type == "cuda"
+        self.host_scores = self.host_index = None
         self.d_index = torch.zeros((w * s,), dtype=torch.int64, device=self.recv.device)
         if self.device.type == "cuda":
             engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
@@ -148,10 +149,27 @@ class ShardedSweep:
                 L.hh_argmax(C.cast(flat[r].data_ptr(), C.POINTER(C.c_float)), per, C.byref(idx))
                 self.d_index[r] = idx.value
 
-    def step(self):
+    def results_to_host(self):
+        """Queue the copy of the gathered scores and the arg-max indices into pinned host buffers (SURVEY.md section 8d
+        counts the result's device-to-host transfer inside the metric).  Asynchronous: complete after the stream is
+        synchronised; ``host_scores`` / ``host_index`` then hold the step's results."""
+        if self.recv.device.type != "cuda":
+            self.host_scores, self.host_index = self.recv, self.d_index
+            return
+        if getattr(self, "host_scores", None) is None:
+            import torch
+
+            self.host_scores = torch.empty(self.recv.shape, dtype=self.recv.dtype, pin_memory=True)
+            self.host_index = torch.empty(self.d_index.shape, dtype=self.d_index.dtype, pin_memory=True)
+        self.host_scores.copy_(self.recv, non_blocking=True)
+        self.host_index.copy_(self.d_index, non_blocking=True)
+
+    def step(self, results_to_host=False):
         self.sweep()
         self.gather()
         self.argmax()
+        if results_to_host:
+            self.results_to_host()
 
     # -- results (these synchronise) ---------------------------------------------------------
     def scores(self) -> np.ndarray:

@@ -511,7 +511,7 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     for res, counters in done:
         out.extend(res)
         if stats is not None:
-            for k in ("launches", "host_syncs", "lsmr_iterations_queued"):
+            for k in ("launches", "host_syncs", "lsmr_iterations_queued", "self_check_failures"):
                 stats[k] = stats.get(k, 0) + counters[k]
             stats["device_bytes"] = stats.get("device_bytes", 0) + counters["device_bytes"]
             stats.setdefault("info", []).extend(counters["info"])

@@ -161,3 +161,19 @@ def test_bench_self_launch_world2_matches_world1(tmp_path):
     weak, sw = _run_bench(tmp_path, 2, ["--scaling", "weak"])
     assert weak["scaling"] == "weak" and weak["config"]["candidates_per_step"] == 200000 and sw.shape == (1, 200000)
     np.testing.assert_array_equal(sw[:, :100000], s1)
+
+
+def test_bench_config_c5_world2_matches_world1(tmp_path):
+    """`bench.py --config C5` (64 segments against one shared grid, per-segment arg-max) at reduced size: 3 segments,
+    every 10th twist — two self-launched ranks over gloo give the one-rank scores and arg-max for every segment."""
+    extra = ["--config", "C5", "--segments", "3", "--grid-stride", "10"]
+    one, s1 = _run_bench(tmp_path, 1, extra)
+    two, s2 = _run_bench(tmp_path, 2, extra)
+    assert s1.shape == (3, 20 * 100) and one["config"]["segments"] == 3 and one["config"]["candidates_per_step"] == 2000
+    assert two["config"]["candidates_per_rank"] == 1000
+    np.testing.assert_array_equal(s1, s2)
+    assert one["argmax"] == two["argmax"] and one["argmax"]["segments"] == 3
+    c4, s4 = _run_bench(tmp_path, 2, ["--config", "C4", "--grid-stride", "50"])
+    assert s4.shape == (1, 10 * 500) and c4["config"]["image"] == 64        # (--side 64 overrides the configuration's 1024)
+    c3, s3 = _run_bench(tmp_path, 2, ["--config", "C3", "--grid-stride", "40"])
+    assert s3.shape == (1, 6 * 10 * 250)
