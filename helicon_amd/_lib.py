@@ -71,6 +71,7 @@ EXPORTS = {
     "hh_create2": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int, C.c_int]),
     "hh_destroy": (None, [_ctx]),
     "hh_max_batch": (C.c_int, [_ctx]),
+    "hh_memory_bytes": (C.c_int64, [_ctx, C.POINTER(C.c_int64)]),
     "hh_last_error": (C.c_char_p, [_ctx]),
     "hh_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "hh_use_own_stream": (C.c_int, [_ctx]),

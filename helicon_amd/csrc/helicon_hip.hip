@@ -2924,6 +2924,23 @@ int ensure_partials(hh_ctx* c, int batch) {
   return HH_OK;
 }
 
+// several segments: the per-batch buffers (masked q [b_pad][K], covariance numerators [N/2+1][b_pad][s_pad], summed
+// moments [b_pad][3]) for batches of up to `batch` candidates.  They only grow, and they are sized by what a sweep really
+// launches — round 2 sized them at hh_set_reference for the largest batch any sweep could use (12.9 GB of q at N = 512 for
+// a 2-segment, 1-candidate call) and cleared all of it on every call.
+int ensure_segment_buffers(hh_ctx* c, int batch) {
+  const int want = (std::max(batch, 64) + 63) / 64 * 64;
+  if (want <= c->b_pad && c->d_q && c->d_cpart && c->d_psum) return HH_OK;
+  const size_t nh = (size_t)(c->n / 2 + 1) * c->n;
+  int rc;
+  if ((rc = ensure_bytes(c, (void**)&c->d_q, &c->cap_q, (size_t)want * nh * sizeof(float)))) return rc;
+  if ((rc = ensure_bytes(c, (void**)&c->d_cpart, &c->cap_cpart, (size_t)(c->n / 2 + 1) * want * c->s_pad * sizeof(float)))) return rc;
+  if ((rc = ensure_bytes(c, (void**)&c->d_psum, &c->cap_psum, (size_t)want * 3 * sizeof(double)))) return rc;
+  HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)want * nh * sizeof(float), c->stream));  // pad rows of a batch stay finite
+  c->b_pad = want;
+  return HH_OK;
+}
+
 // several segments: candidates per launch of the shared-twist pipelines (q of a batch lives in HBM)
 inline int seg_batch(int n) {
   const int64_t per = (int64_t)(n / 2 + 1) * n * (int64_t)sizeof(float);
@@ -2943,6 +2960,10 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
   const int bmax = !plan.fused ? c->max_batch
                    : (int)std::min<int64_t>(c->n_segments == 1 ? std::max(c->max_batch, fused_cap) : std::max(c->max_batch, seg_batch(c->n)),
                                             std::max<int64_t>(count_cand, 16));
+  if (c->n_segments > 1) {
+    const int rcs = ensure_segment_buffers(c, bmax);
+    if (rcs) return rcs;
+  }
   const int64_t per_batch = plan.len <= bmax ? bmax / plan.len : 1;
   const size_t run_bytes = (size_t)plan.rows * nky * sizeof(float2);
   int64_t per_group = std::max<int64_t>(1, (int64_t)(HH_TABLE_BYTES_MAX / run_bytes));
@@ -3396,6 +3417,37 @@ void hh_destroy(hh_ctx* c) {
 
 int hh_max_batch(const hh_ctx* c) { return c ? c->max_batch : HH_ERR_ARG; }
 
+// Device memory the context holds right now (its buffers grow with the sweeps it has run and are kept until
+// hh_destroy): the sizes the runtime reports for its allocations.  out (may be NULL): {run tables, column factors,
+// two-pass intermediate, several-segment buffers (q + covariance numerators), everything else}.
+int64_t hh_memory_bytes(const hh_ctx* c, int64_t out[5]) {
+  if (!c) return HH_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  auto size_of = [](const void* p) -> int64_t {
+    size_t n = 0;
+    return (p && hipMemPtrGetInfo(const_cast<void*>(p), &n) == hipSuccess) ? (int64_t)n : 0;
+  };
+  int64_t part[5] = {0, 0, 0, 0, 0};
+  part[0] = size_of(c->d_table);
+  part[1] = size_of(c->d_eg) + size_of(c->d_cgs);
+  part[2] = size_of(c->d_inter);
+  part[3] = size_of(c->d_q) + size_of(c->d_cpart) + size_of(c->d_wec) + size_of(c->d_psum);
+  for (const void* p : {(const void*)c->d_tw, (const void*)c->d_partials, (const void*)c->d_params, (const void*)c->d_scores, (const void*)c->d_units,
+                        (const void*)c->d_w2, (const void*)c->d_ref, (const void*)c->d_kb_list, (const void*)c->d_run_imax, (const void*)c->d_argmax,
+                        (const void*)c->d_spec, (const void*)c->d_img})
+    part[4] += size_of(p);
+  if (const hh_gen* g = c->gen) {
+    part[0] += size_of(g->d_table);
+    part[1] += size_of(g->d_eg) + size_of(g->d_cgs);
+    for (const void* p : {(const void*)g->d_tw_nx, (const void*)g->d_tw_ny, (const void*)g->d_w2, (const void*)g->d_runs, (const void*)g->d_run_of,
+                          (const void*)g->d_layers, (const void*)g->d_partials, (const void*)g->d_r, (const void*)g->d_f, (const void*)g->d_cent})
+      part[4] += size_of(p);
+  }
+  int64_t total = 0;
+  for (int k = 0; k < 5; ++k) { total += part[k]; if (out) out[k] = part[k]; }
+  return total;
+}
+
 // The fused pass's launch plan for `runs` runs of `run_len` candidates, `n_kb` ky blocks and `slots` resident workgroups
 // (pure host arithmetic, no device needed): out = {runs_a, groups_a, cpw_a, groups_b, cpw_b, layers}.
 int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]) {
@@ -3534,7 +3586,6 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   const int s_pad = multi ? (n_segments + 63) / 64 * 64 : 0;
   // several segments: the shared-twist pipelines batch up to HH_SEG_BATCH candidates (q of a batch lives in HBM:
   // 0.5 MB per candidate at N = 512), the general pipeline max_batch
-  const int b_pad = multi ? (std::max(c->max_batch, seg_batch(c->n)) + 63) / 64 * 64 : 0;
   std::vector<float2> w2(nh);
   std::vector<float> wecm(multi ? (size_t)s_pad * nh : 0, 0.f);
   c->ref.assign(n_segments, RefConsts{});
@@ -3571,14 +3622,10 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   HH_HIP(c, hipMemcpyAsync(c->d_w2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
   if (multi) {
     if ((rcg = ensure_bytes(c, (void**)&c->d_wec, &c->cap_wec, wecm.size() * sizeof(float)))) return rcg;
-    if ((rcg = ensure_bytes(c, (void**)&c->d_q, &c->cap_q, (size_t)b_pad * nh * sizeof(float)))) return rcg;
-    if ((rcg = ensure_bytes(c, (void**)&c->d_cpart, &c->cap_cpart, (size_t)(n / 2 + 1) * b_pad * s_pad * sizeof(float)))) return rcg;
     if ((rcg = ensure_bytes(c, (void**)&c->d_ref, &c->cap_ref, (size_t)n_segments * sizeof(RefConsts)))) return rcg;
-    if ((rcg = ensure_bytes(c, (void**)&c->d_psum, &c->cap_psum, (size_t)b_pad * 3 * sizeof(double)))) return rcg;  // one triple per candidate of a batch
     HH_HIP(c, hipMemcpyAsync(c->d_wec, wecm.data(), wecm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HH_HIP(c, hipMemcpyAsync(c->d_ref, c->ref.data(), (size_t)n_segments * sizeof(RefConsts), hipMemcpyHostToDevice,
                              c->stream));
-    HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)b_pad * nh * sizeof(float), c->stream));  // pad rows stay finite
   }
   if ((rcg = ensure_bytes(c, (void**)&c->d_kb_list, &c->cap_kb, (size_t)(n / 16) * sizeof(int)))) return rcg;
   HH_HIP(c, hipMemcpyAsync(c->d_kb_list, kb_list.data(), kb_list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -3586,8 +3633,11 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   HH_HIP(c, hipMemsetAsync(c->d_partials, 0, (size_t)2 * c->cap_partials * npart_for(n) * 3 * sizeof(double), c->stream));
   c->n_kb = (int)kb_list.size();
   c->kb_mask = kb_mask;
+  if (s_pad != c->s_pad) {   // the covariance buffer's row length changes with the segment count: start over
+    c->b_pad = 0;
+  }
   c->s_pad = s_pad;
-  c->b_pad = b_pad;
+  if (multi && (rcg = ensure_segment_buffers(c, c->max_batch))) return rcg;   // the general pipeline's batches; shared-twist sweeps grow it
   HH_HIP(c, hipStreamSynchronize(c->stream));
   c->n_segments = n_segments;
   c->log_flag = log_flag ? 1 : 0;

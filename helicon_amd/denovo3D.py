@@ -377,6 +377,13 @@ class SweepEngine:
         with self._lock:
             self._check(self._L.hh_calibrate_traffic(self._ctx, int(mode), int(nbytes)))
 
+    def memory_bytes(self) -> dict:
+        """Device memory this engine holds right now (``hh_memory_bytes``): total and its parts."""
+        parts = (C.c_int64 * 5)()
+        total = self._L.hh_memory_bytes(self._ctx, parts)
+        names = ("run_tables", "column_factors", "intermediate", "segment_buffers", "other")
+        return dict(total=int(total), **{k: int(v) for k, v in zip(names, parts)})
+
     def algorithmic_bytes(self) -> int:
         return 4 * self.ny * self.nx + 16 * self.nx * (self.ny // 2 + 1)  # = hh_algorithmic_bytes(n) for a square
 

@@ -99,6 +99,11 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch);
 void hh_destroy(hh_ctx* ctx);
 /* candidates per kernel launch this context was created with (the resolved default). */
 int hh_max_batch(const hh_ctx* ctx);
+/* Device memory the context holds right now (bytes; its buffers grow with the sweeps it has run and stay until
+ * hh_destroy).  parts (may be NULL): {run tables, column factors, two-pass intermediate, several-segment buffers,
+ * everything else}.  Typical: C2 (512^2, one 100k launch) 0.21 + 2.9 + 0.27 GB; C4 (1024^2) ~7 GB; C5 (64 segments x
+ * 20k candidates) ~12 GB of masked spectra. */
+int64_t hh_memory_bytes(const hh_ctx* ctx, int64_t parts[5]);
 /* How hh_sweep cuts a launch of the fused pipeline into workgroups: `runs` runs of `run_len`
  * candidates, `n_kb` ky blocks, `slots` workgroups resident on the device at a time.  The first runs_a runs are cut into
  * groups_a layers of cpw_a candidates each, the others into groups_b layers of cpw_b; out = {runs_a, groups_a, cpw_a,

@@ -328,3 +328,25 @@ def test_fused_launch_schedules_agree_with_the_transform_pipeline(n, n_twists, n
     want = eng.sweep(params[pick])
     assert np.isfinite(got).all()
     np.testing.assert_allclose(got[:, pick], want, rtol=0, atol=5e-5)
+
+
+def test_memory_report_and_segment_buffers_follow_the_sweep():
+    """hh_memory_bytes: a context reports what it holds; the several-segment buffers are sized by the sweeps that ran, not
+    by the largest batch any sweep could use (round 2: 12.9 GB of masked spectra for a 2-segment, 1-candidate call)."""
+    eng = H.SweepEngine(512)
+    eng.set_geometry(apix=1.0, helical_diameter=0.4 * 512, ball_radius=2.0)
+    clean = eng.simulate(1.2, 4.75, 1)
+    m0 = eng.memory_bytes()
+    assert m0["total"] == sum(v for k, v in m0.items() if k != "total") and m0["segment_buffers"] == 0
+    eng.set_reference(np.stack([clean, clean[::-1].copy()]))
+    one = eng.sweep(np.array([[1.2, 4.75, 1, 0.0]]))
+    assert one.shape == (2, 1) and one[0, 0] > 0.99
+    m1 = eng.memory_bytes()
+    assert 0 < m1["segment_buffers"] < 2**30, m1
+    g = H.build_grid(H.sweep_axis(1.0, 1.4, 0.02), H.sweep_axis(4.5, 5.0, 0.005), (1,), tube_length=512.0)   # 21 x 101 runs
+    sc = eng.sweep(g.params)
+    m2 = eng.memory_bytes()
+    assert eng.last_first_pass == "fused" and m2["segment_buffers"] > m1["segment_buffers"] and m2["run_tables"] > 0
+    assert int(np.argmax(sc[0])) == int(np.argmin(np.abs(g.params[:, 0] - 1.2) + np.abs(g.params[:, 1] - 4.75)))
+    np.testing.assert_allclose(eng.sweep(np.array([[1.2, 4.75, 1, 0.0]])), one, rtol=0, atol=1e-6)   # the grown buffers serve small calls
+    eng.close()
