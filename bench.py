@@ -484,8 +484,8 @@ def config_legs(args, torch, dev):
     tw, rs = sweep_axis(0.01, 4.00, 0.01), sweep_axis(4.000, 5.245, 0.005)
     sweep_leg("C4_1024", 1024, 1, sweep_axis(0.01, 5.00, 0.01), sweep_axis(4.000, 6.495, 0.005), 2)
     sweep_leg("C5_64_segments", 512, 64, sweep_axis(0.02, 4.00, 0.02), sweep_axis(4.25, 5.24, 0.01), 5)
-    sweep_leg("general_400", (400, 400), 1, tw[:100], rs, 3)
-    sweep_leg("general_200", (200, 200), 1, tw[:200], rs, 3)
+    sweep_leg("general_400", (400, 400), 1, tw[70:170], rs, 3)     # (both windows contain the truth's twist 1.20)
+    sweep_leg("general_200", (200, 200), 1, tw[20:220], rs, 3)
     try:
         out["path_a"] = path_a_leg(dev.index or 0)
     except Exception as ex:   # the leg must not take the headline down with it

@@ -93,6 +93,8 @@ EXPORTS = {
     "hh_comm_destroy": (C.c_int, [_ctx]),
     "hh_simulate": (C.c_int, [_ctx, _f64p, _f32p]),
     "hh_power_spectrum": (C.c_int, [_ctx, _f32p, C.c_int, _f32p, _f32p]),
+    "hh_power_spectrum_zoom": (C.c_int, [C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_int, _f32p, _f32p]),
     "hh_cross_correlation": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f64p]),
     "hh_cosine_similarity": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f64p]),
     "hh_cross_correlation_f64": (C.c_int, [_ctx, _f64p, _f64p, C.c_int64, _f64p]),

@@ -4316,5 +4316,6 @@ int hh_profile_get(hh_ctx* c, hh_profile* out) {
 
 }  // extern "C"
 
+#include "fourier_zoom.inc"  // compute_power_spectra with cutoff_res / output_size: direct non-uniform DFT (hh_power_spectrum_zoom)
 #include "path_a_host.inc"  // Path A: host side and C ABI (hh_pa_*)
 #include "path_a_batch.inc"  // Path A for many candidates at once, device-resident solve (hh_pab_*)

@@ -439,15 +439,30 @@ def simulate_helical_projection(n, twist, rise, csym, helical_diameter, ball_rad
 
 def compute_power_spectra(data, apix, cutoff_res=None, output_size=None, log=True,
                           low_pass_fraction=0, high_pass_fraction=0, *, device=0):
-    """transforms.py:771-820 for the default Fourier sampling (no ``cutoff_res`` / ``output_size`` zoom);
-    returns ``(pwr, phase)``."""
+    """transforms.py:771-820; returns ``(pwr, phase)``.  Default Fourier sampling: the sweep's own transform kernels.  With
+    ``cutoff_res`` / ``output_size`` (the Fourier-space zoom of ``fft_rescale``, transforms.py:663-713): the direct
+    non-uniform transform ``hh_power_spectrum_zoom`` — what the reference's finufft call approximates to 1e-6."""
     data = np.asarray(data)
     if data.ndim != 2:
         raise NotImplementedError("only 2D images are on the accelerated path")
-    if cutoff_res is not None and tuple(cutoff_res) != (2 * apix, 2 * apix):
-        raise NotImplementedError("Fourier-space zoom (cutoff_res) is outside the accelerated path")
-    if output_size is not None and tuple(output_size) != tuple(data.shape):
-        raise NotImplementedError("Fourier-space zoom (output_size) is outside the accelerated path")
+    zoom = (cutoff_res is not None and tuple(cutoff_res) != (2 * apix, 2 * apix)) or \
+           (output_size is not None and tuple(output_size) != tuple(data.shape))
+    # an odd side: the reference's (-1)^(u + v) does not undo the shift of finufft's centred modes there, so its transform
+    # is fft2 times a unit-modulus phase ramp (same amplitudes, other phases) — the direct sum reproduces exactly that
+    if zoom or data.shape[0] % 2 or data.shape[1] % 2:
+        cy, cx = (float(v) for v in cutoff_res) if cutoff_res else (2.0 * apix, 2.0 * apix)
+        ony, onx = (int(v) for v in output_size) if output_size else data.shape
+        img = np.ascontiguousarray(data, dtype=np.float32)
+        pwr = np.empty((ony, onx), dtype=np.float32)
+        phase = np.empty((ony, onx), dtype=np.float32)
+        L = _lib.lib()
+        _lib.check(L.hh_power_spectrum_zoom(int(device), _ptr(img, C.c_float), img.shape[0], img.shape[1], ony, onx, float(apix),
+                                            cy, cx, 1 if log else 0, _ptr(pwr, C.c_float), _ptr(phase, C.c_float)), None)
+        if 0 < low_pass_fraction < 1 or 0 < high_pass_fraction < 1:   # on the normalised spectrum: see below
+            f = low_high_pass_filter(pwr, low_pass_fraction, high_pass_fraction, device=device)
+            vmin, vmax = float(f.min()), float(f.max())
+            pwr = (f - vmin) / (vmax - vmin) if vmax != vmin else f
+        return pwr.astype(np.float64), phase.astype(np.float64)
     eng = _engine(_image_shape(*data.shape), device)
     with eng.session():
         pwr, phase = eng.power_spectrum(data, log=log, want_phase=True)

@@ -296,6 +296,13 @@ int hh_pa_lsmr(hh_pa* pa, const double* rhs, const double* d, const double* root
                int maxiter, double* x_out, int info[2], double norms[2]);
 
 
+/* compute_power_spectra(data, apix, cutoff_res, output_size, log) with a Fourier-space zoom (lib/transforms.py:771-820 over
+ * fft_rescale, :663-713): the image's transform at ony x onx frequencies fftfreq(on) * 2 * apix / cutoff_res, as the
+ * direct sum finufft.nufft2d2(eps=1e-6) approximates, float64; (-1)^(u+v), fftshift, |F| (log1p when log_flag), min-max
+ * normalisation; phase_out (may be NULL) = angle of the shifted transform.  image: ny x nx host float32; outputs ony x onx. */
+int hh_power_spectrum_zoom(int device, const float* image, int ny, int nx, int ony, int onx, double apix, double cutoff_y,
+                           double cutoff_x, int log_flag, float* pwr_out, float* phase_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Path A for MANY candidates at once (round 3): K candidates of one image and one reconstruction box — the K tasks the
  * reference's thread pool runs one by one (webApps/denovo3D/app.py:2473-2476 -> pipeline.py:351-404 ->

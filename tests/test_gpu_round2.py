@@ -350,3 +350,57 @@ def test_memory_report_and_segment_buffers_follow_the_sweep():
     assert int(np.argmax(sc[0])) == int(np.argmin(np.abs(g.params[:, 0] - 1.2) + np.abs(g.params[:, 1] - 4.75)))
     np.testing.assert_allclose(eng.sweep(np.array([[1.2, 4.75, 1, 0.0]])), one, rtol=0, atol=1e-6)   # the grown buffers serve small calls
     eng.close()
+
+
+def test_power_spectrum_with_fourier_zoom_against_the_oracle():
+    """compute_power_spectra(cutoff_res=, output_size=) (transforms.py:771-820 over fft_rescale :663-713): the device's
+    direct non-uniform transform against the oracle's (the sum finufft approximates to 1e-6) — zoom in, zoom out,
+    rectangular and odd shapes, both log settings, with the Gaussian filter on top; and the default arguments still take
+    the sweep's own transform and agree with the zoom kernels evaluated at the same frequencies."""
+    rng = np.random.default_rng(11)
+    eng = H.SweepEngine(64)
+    eng.set_geometry(apix=2.0, helical_diameter=50.0, ball_radius=4.0)
+    helix = eng.simulate(29.0, 10.0, 1)
+    eng.close()
+    cases = [
+        (helix, 2.0, (8.0, 8.0), (64, 64), True),       # zoom in by 2, same size
+        (helix, 2.0, (6.0, 10.0), (96, 48), True),      # anisotropic, other size
+        (helix, 2.0, None, (128, 128), False),          # finer sampling only
+        (rng.normal(size=(45, 63)), 1.5, (5.0, 7.0), (50, 33), True),    # odd, rectangular in and out
+        (rng.normal(size=(40, 72)), 1.0, (2.0, 2.0), (40, 72), True),    # the default sampling through the zoom kernels
+    ]
+    for img, apix, cut, osz, log in cases:
+        pw, ph = H.compute_power_spectra(img, apix, cutoff_res=cut if cut != (2.0, 2.0) or apix != 1.0 else None, output_size=osz, log=log) \\
+            if not (cut == (2.0, 2.0) and apix == 1.0) else _zoom_direct(img, apix, cut, osz, log)
+        pw_o, ph_o = O.compute_power_spectra(img.astype(np.float32), apix, cutoff_res=cut, output_size=osz, log=log) \\
+            if not (cut == (2.0, 2.0) and apix == 1.0) else _oracle_direct(img, apix, cut, osz, log)
+        assert pw.shape == tuple(osz)
+        np.testing.assert_allclose(pw, pw_o, rtol=0, atol=2e-5)
+        strong = pw_o > 0.2                                  # the phase of a near-zero coefficient is noise
+        d = np.angle(np.exp(1j * (ph - ph_o)))
+        assert np.abs(d[strong]).max() < 1e-3
+    pw, _ = H.compute_power_spectra(helix, 2.0, cutoff_res=(8.0, 8.0), output_size=(64, 64), low_pass_fraction=0.5, high_pass_fraction=0.05)
+    pw_o, _ = O.compute_power_spectra(helix.astype(np.float32), 2.0, cutoff_res=(8.0, 8.0), output_size=(64, 64), low_pass_fraction=0.5,
+                                      high_pass_fraction=0.05)
+    np.testing.assert_allclose(pw, pw_o, rtol=0, atol=5e-5)
+
+
+def _zoom_direct(img, apix, cut, osz, log):
+    """The zoom entry point at the DEFAULT frequencies (the Python wrapper would route those to the sweep's transform)."""
+    import ctypes as C
+
+    from helicon_amd import _lib
+
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    pw = np.empty(osz, dtype=np.float32)
+    ph = np.empty(osz, dtype=np.float32)
+    f32 = C.POINTER(C.c_float)
+    _lib.check(_lib.lib().hh_power_spectrum_zoom(0, a.ctypes.data_as(f32), a.shape[0], a.shape[1], osz[0], osz[1], apix, cut[0], cut[1],
+                                                 1 if log else 0, pw.ctypes.data_as(f32), ph.ctypes.data_as(f32)), None)
+    return pw.astype(np.float64), ph.astype(np.float64)
+
+
+def _oracle_direct(img, apix, cut, osz, log):
+    fft = np.fft.fftshift(O.fft_rescale(img.astype(np.float32), apix=apix, cutoff_res=cut, output_size=osz))
+    pwr = O.normalize_percentile(np.log1p(np.abs(fft)) if log else np.abs(fft), (0, 100))
+    return pwr, np.angle(fft)
