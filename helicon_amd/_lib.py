@@ -56,6 +56,7 @@ class hh_pa_params(C.Structure):
         ("reconstruct_length_3d_pixel", C.c_int32),
         ("min_projection_lines", C.c_int64), ("min_sym_pairs", C.c_int64),
         ("interpolation", C.c_int32), ("fsc_mode", C.c_int32), ("fsc_half", C.c_int32),
+        ("n_fsc_ids", C.c_int32), ("fsc_ids", C.POINTER(C.c_int32)),
     ]
 
 

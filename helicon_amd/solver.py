@@ -457,18 +457,37 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     ``return_3d=False``).  ``stats``, if a dict, receives launch / synchronisation counters."""
     img = np.asarray(projection_image)
     cands = [(float(t), float(r), int(c)) for t, r, c in candidates]
-    if fsc_test == 1:
-        raise NotImplementedError("fsc_test=1 (random halves) goes through lsq_reconstruct")
     d2, l2, d3, l3, mask, n3, target = _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel,
                                             reconstruct_diameter_3d_pixel, reconstruct_length_3d_pixel,
                                             reconstruct_diameter_3d_inner_pixel, sym_oversample)
+    random_split = fsc_test == 1     # solver:186-189: halves from np.random.shuffle of the pixel ids (global RNG)
     halves = (0, 1, 2) if fsc_test and fsc_test > 1 else (0,)
-    per = len(halves)
+    per = 3 if fsc_test and fsc_test >= 1 else 1
     step = max(1, int(batch) // per)
+    if random_split:
+        streams = 1                  # the draws follow the order of the list
     # groups of equal size rather than full groups and a remainder; a short list is still spread over the streams (a
     # group of a dozen candidates already fills its launches' latency)
     n_groups = max(1, -(-len(cands) // step), min(int(streams), len(cands) // 12))
     bounds = [round(k * len(cands) / n_groups) for k in range(n_groups + 1)]
+
+    def params_of(tw, rs, cs, mode, half, ids=None):
+        q = hh_pa_params(float(scale2d_to_3d), tw, rs, cs, float(tilt_degree), float(psi_degree), float(dy_pixel), d2, l2, d3,
+                         int(reconstruct_diameter_3d_inner_pixel), l3, int(target), int(target), 0, int(mode) if half else 0, half)
+        if ids is not None:
+            q.n_fsc_ids = len(ids)
+            q.fsc_ids = ids.ctypes.data_as(C.POINTER(C.c_int32))
+        return q
+
+    def solve_batch(params, positive):
+        with PathABatch(img, params, device=device) as B:
+            if B.n != n3:
+                raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
+                                 "the 3-D diameter): the reference's two masks would rank the voxels differently")
+            x, scores, info = B.solve(positive, 1 if thresh_fraction >= 0 else 0, want_x=return_3d)
+            pids = [B.rhs(c)[1] for c in range(len(params))] if random_split else None
+            counters = dict(B.counters(), device_bytes=B.device_bytes, info=info.tolist())
+        return x, scores, counters, pids
 
     def run_group(g):
         chunk = cands[bounds[g]: bounds[g + 1]]
@@ -477,16 +496,29 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
             pitch_pixel = round(rs * 360 / abs(tw))
             pos = positive_constraint > 0 or (positive_constraint < 0 and pitch_pixel > round(l3 * 2))    # solver:352-355
             for half in halves:
-                params.append(hh_pa_params(float(scale2d_to_3d), tw, rs, cs, float(tilt_degree), float(psi_degree),
-                                           float(dy_pixel), d2, l2, d3, int(reconstruct_diameter_3d_inner_pixel), l3,
-                                           int(target), int(target), 0, int(fsc_test) if half else 0, half))
+                params.append(params_of(tw, rs, cs, fsc_test, half))
                 positive.append(1 if pos else 0)
-        with PathABatch(img, params, device=device) as B:
-            if B.n != n3:
-                raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
-                                 "the 3-D diameter): the reference's two masks would rank the voxels differently")
-            x, scores, info = B.solve(positive, 1 if thresh_fraction >= 0 else 0, want_x=return_3d)
-            counters = dict(B.counters(), device_bytes=B.device_bytes, info=info.tolist())
+        x, scores, counters, pids = solve_batch(params, positive)
+        if random_split:
+            # the whole-image solves above, then the two halves of every candidate's pixels: list(set(ids)) in the set's own
+            # order, shuffled by the global NumPy RNG, first half of the shuffled ids against the rest
+            keep, params2, positive2 = [], [], []
+            for k, (tw, rs, cs) in enumerate(chunk):
+                ids = list(set(pids[k]))
+                np.random.shuffle(ids)
+                first = np.ascontiguousarray(ids[: len(ids) // 2], dtype=np.int32)
+                keep.append(first)
+                for half in (1, 2):
+                    params2.append(params_of(tw, rs, cs, 1, half, first))
+                    positive2.append(positive[k])
+            x2, scores2, counters2, _ = solve_batch(params2, positive2)
+            for key in ("launches", "host_syncs", "lsmr_iterations_queued", "self_check_failures"):
+                counters[key] += counters2[key]
+            counters["info"] += counters2["info"]
+            # interleave: (full, half 1, half 2) per candidate
+            scores = np.stack([scores, scores2[0::2], scores2[1::2]], axis=1).reshape(-1)
+            if return_3d:
+                x = np.stack([x, x2[0::2], x2[1::2]], axis=1).reshape(-1, x.shape[1])
         res = []
         for k in range(len(chunk)):
             sc = scores[k * per: (k + 1) * per]
@@ -537,8 +569,8 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
         raise ValueError("interpolation must be 'nn' or 'linear'")
     if (algorithm or {}).get("model", "lsq") != "lsq":
         raise NotImplementedError("the GPU slice of Path A provides model='lsq' (the scikit-learn models are not deterministic)")
-    if fsc_test == 1:
-        raise NotImplementedError("fsc_test=1 is the reference's random split of the pixels (np.random.shuffle of a set)")
+    if fsc_test == 1 and interpolation != "nn":
+        raise NotImplementedError("fsc_test=1 (the random split of the pixels) is provided with interpolation='nn'")
     if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
         raise NotImplementedError("scores other than cosine need scikit-image")
     if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):

@@ -277,7 +277,10 @@ typedef struct hh_pa_params {
                                      trilinear weights, rays recomputed in every product, 16-entry symmetry rows) */
   int32_t fsc_mode, fsc_half;     /* half sets of lsq_reconstruct's fsc_test (split_A_b, solver:175-203): fsc_half 0 = all
                                      data rows, 1 / 2 = the rows of the first / second half of the pixel ids under
-                                     fsc_mode 2 (every second id), 3 (lower / upper half), >= 4 (outer / middle thirds) */
+                                     fsc_mode 2 (every second id), 3 (lower / upper half), >= 4 (outer / middle thirds),
+                                     1 (the ids listed in fsc_ids / the others: the caller's random split, :186-189) */
+  int32_t n_fsc_ids;              /* fsc_mode 1 only: number of pixel ids (k * D2d + j) in the first half ... */
+  const int32_t* fsc_ids;         /* ... and the ids, any order; read during the create call only */
 } hh_pa_params;
 int hh_pa_create(hh_pa** out, int device, const float* image, int ny, int nx, const hh_pa_params* params);
 void hh_pa_destroy(hh_pa* pa);

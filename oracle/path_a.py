@@ -774,13 +774,18 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     score = cosine_similarity(pred, b_data)
     rec3d = np.zeros(mask.shape, dtype=np.float32)
     rec3d[mask] = x
-    if fsc_test and fsc_test > 1:
+    if fsc_test and fsc_test >= 1:
         # split_A_b (solver:175-203), deterministic modes: the rows of every second pixel id (2), of the lower half of the
         # ids (3), of the outer thirds (4+) against the rest; each half is solved with the same symmetry block and its
         # own upper bound; score = s0 / 2 + (s1 + s2) / 4 (solver:526-529)
         ids = sorted(set(b_pid.tolist()))
         n = len(ids)
-        set1 = ids[::2] if fsc_test == 2 else ids[: n // 2] if fsc_test == 3 else ids[: n // 3] + ids[n * 2 // 3:]
+        if fsc_test == 1:   # solver:186-189: the ids in the set's own iteration order, shuffled by the global RNG
+            ids = list(set(b_pid))
+            np.random.shuffle(ids)
+            set1 = ids[: n // 2]
+        else:
+            set1 = ids[::2] if fsc_test == 2 else ids[: n // 3] + ids[n * 2 // 3:] if fsc_test >= 4 else ids[: n // 2]
         is1 = np.isin(b_pid, set1)
         halves, scores = [], [score]
         for sel in (is1, ~is1):

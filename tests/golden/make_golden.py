@@ -497,10 +497,53 @@ def g11_fsc_halves():
     np.savez_compressed(OUT / "g11_fsc_halves.npz", **out)
 
 
+def g12_polymer():
+    """simulate_helical_projection(polymer=1) (utils.py:125-136 over random_polymer, :192-333), replayed from
+    np.random.seed: the random-walk asymmetric unit itself (as the lattice code receives it) and the projection."""
+    out = {}
+    cases = [  # (seed, n, twist, rise, csym, diameter, ball_radius, planarity, ny, nx, apix, tilt, psi, dy)
+        (7, 10, 30.0, 5.0, 1, 40.0, 3.0, 0.9, 32, 32, 2.0, 0, 0, 0),          # the reference's own test (test_denovo3D_utils.py:145)
+        (8, 12, -20.0, 6.0, 2, 60.0, 3.0, 0.5, 48, 64, 2.0, 0, 0, 0),
+        (9, 8, 41.0, 9.0, 3, 50.0, 2.5, 0.0, 64, 64, 2.0, 4.0, -3.0, 1.5),
+    ]
+    for k, c in enumerate(cases):
+        seed, n, tw, rs, cs, d, br, pl, ny, nx, apix, tilt, psi, dy = c
+        np.random.seed(seed)
+        centers = utils.random_polymer(n_atoms=n, rmin=0, rmax=d / 2, csym=cs, planarity=pl)
+        np.random.seed(seed)
+        img = utils.simulate_helical_projection(n, tw, rs, cs, d, br, 1, pl, ny, nx, apix, tilt=tilt, psi=psi, dy=dy)
+        out[f"case{k}_args"] = np.asarray(c, dtype=np.float64)
+        out[f"case{k}_polymer"] = centers
+        out[f"case{k}_out"] = img
+        print("g12", k, centers.shape, float(img.max()))
+    out["n_cases"] = np.asarray([len(cases)])
+    np.savez_compressed(OUT / "g12_polymer.npz", **out)
+
+
+def g13_fsc_random():
+    """lsq_reconstruct with fsc_test = 1 (solver:186-189: the pixel ids as list(set(.)), np.random.shuffle, first half),
+    replayed from np.random.seed, on the helix of fixture G9."""
+    from helicon.webApps.denovo3D.solver_linear_regression import lsq_reconstruct
+
+    g9 = np.load(OUT / "g9_process_one_task.npz")
+    img = g9["image"]
+    out = {"image": img}
+    for k, seed in enumerate((3, 11)):
+        np.random.seed(seed)
+        (rec, r1, r2), score = lsq_reconstruct(img, 1.0, 29.0, 2.0, 1, reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20,
+                                               reconstruct_length_2d_pixel=48, reconstruct_length_3d_pixel=6, sym_oversample=1,
+                                               interpolation="nn", fsc_test=1, algorithm={"model": "lsq"})
+        out[f"seed{k}"] = np.array([seed])
+        out[f"seed{k}_score"] = np.array([score])
+        out[f"seed{k}_rec"], out[f"seed{k}_rec1"], out[f"seed{k}_rec2"] = rec, r1, r2
+        print("g13 seed", seed, score)
+    np.savez_compressed(OUT / "g13_fsc_random.npz", **out)
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves]
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:
         if not only or make.__name__ in only:

@@ -72,8 +72,22 @@ def test_simulate_larger_sizes(n, apix, tw, rs, cs, rot):
 def test_simulate_reference_error_behaviour():
     with pytest.raises(AssertionError):  # utils.py:88
         H.simulate_helical_projection(1, 30, 5, 1, 64, 3, 0, 0, 32, 32, 2.0)
-    with pytest.raises(NotImplementedError):
-        H.simulate_helical_projection(10, 30, 5, 1, 40, 3, 1, 0.9, 32, 32, 2.0)
+    with pytest.raises(ValueError):      # the device lattice takes up to 64 atoms per asymmetric unit
+        H.simulate_helical_projection(40, 30, 5, 2, 40, 3, 1, 0.9, 32, 32, 2.0)
+
+
+def test_simulate_with_a_random_polymer_replays_the_reference(golden_dir):
+    """polymer=1 (utils.py:125-136 over random_polymer, :192-333; fixture G12, made with np.random.seed): the host-side
+    walk draws the reference's atoms, the device lattice + raster give the reference's projection (csym 1, 2, 3; with
+    tilt / psi / dy)."""
+    g = np.load(golden_dir / "g12_polymer.npz")
+    for k in range(int(g["n_cases"][0])):
+        seed, n, tw, rs, cs, d, br, pl, ny, nx, apix, tilt, psi, dy = g[f"case{k}_args"]
+        np.random.seed(int(seed))
+        out = H.simulate_helical_projection(int(n), tw, rs, int(cs), d, br, 1, pl, int(ny), int(nx), apix, tilt=tilt, psi=psi, dy=dy)
+        ref = g[f"case{k}_out"]
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out, ref, rtol=0, atol=5e-6 * max(1.0, ref.max()))
 
 
 # ---------------------------------------------------------------------------- B2 spectrum
@@ -99,10 +113,10 @@ def test_power_spectrum_of_structured_image_and_unsupported_options():
     pwr, _ = H.compute_power_spectra(img, 2.0)
     rp, _ = O.compute_power_spectra(img.astype(np.float64), 2.0)
     np.testing.assert_allclose(pwr, rp, rtol=0, atol=2e-5)
-    with pytest.raises(NotImplementedError):
-        H.compute_power_spectra(img, 2.0, cutoff_res=(8.0, 8.0))
-    with pytest.raises(NotImplementedError):
-        H.compute_power_spectra(img, 2.0, output_size=(64, 64))
+    zp, _ = H.compute_power_spectra(img, 2.0, cutoff_res=(8.0, 8.0))          # the Fourier zoom (tests/test_gpu_round2.py)
+    zo, _ = O.compute_power_spectra(img.astype(np.float64), 2.0, cutoff_res=(8.0, 8.0))
+    np.testing.assert_allclose(zp, zo, rtol=0, atol=2e-5)
+    assert H.compute_power_spectra(img, 2.0, output_size=(64, 64))[0].shape == (64, 64)
     with pytest.raises(ValueError):
         H.compute_power_spectra(np.zeros((4, 96), np.float32), 2.0)       # sides below 8
 

@@ -307,8 +307,8 @@ def test_half_set_solves_reproduce_the_reference(golden_dir):
         for got, name in ((rec, "rec"), (r1, "rec1"), (r2, "rec2")):
             want = g[f"mode{mode}_{name}"]
             assert got.shape == want.shape and np.abs(got - want).max() < 1e-2 * np.abs(want).max(), (mode, name)
-    with pytest.raises(NotImplementedError):
-        lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **kw)
+    with pytest.raises(NotImplementedError):     # the random split is provided with the nearest-neighbour projector
+        lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **dict(kw, interpolation="linear"))
     # the halves partition the data rows
     from helicon_amd.solver import PathAProblem
     base = dict(scale2d_to_3d=1.0, twist_degree=29.0, rise_pixel=2.0, csym=1, tilt_degree=0, psi_degree=0, dy_pixel=0,
@@ -319,5 +319,28 @@ def test_half_set_solves_reproduce_the_reference(golden_dir):
         assert P1.m_data + P2.m_data == P0.m_data and P1.m_sym == P2.m_sym == P0.m_sym
         assert sorted(np.r_[P1.b_pid, P2.b_pid].tolist()) == sorted(P0.b_pid.tolist())
         assert not set(P1.b_pid.tolist()) & set(P2.b_pid.tolist())
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):              # mode 1 needs the first half's pixel ids
         PathAProblem(g["image"], fsc_mode=1, fsc_half=1, **base)
+
+
+def test_random_half_sets_replay_the_reference(golden_dir):
+    """lsq_reconstruct(fsc_test=1) (solver:186-189: list(set(pixel ids)), np.random.shuffle, first half; fixture G13, made
+    with np.random.seed): the same seed gives the reference's split, hence its half maps and combined score."""
+    g = np.load(golden_dir / "g13_fsc_random.npz")
+    kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=48,
+              reconstruct_length_3d_pixel=6, sym_oversample=1, interpolation="nn")
+    for k in (0, 1):
+        np.random.seed(int(g[f"seed{k}"][0]))
+        (rec, r1, r2), score = lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **kw)
+        assert score == pytest.approx(float(g[f"seed{k}_score"][0]), abs=1e-4)
+        for got, name in ((rec, "rec"), (r1, "rec1"), (r2, "rec2")):
+            want = g[f"seed{k}_{name}"]
+            assert got.shape == want.shape and np.abs(got - want).max() < 1e-2 * np.abs(want).max(), (k, name)
+        np.random.seed(int(g[f"seed{k}"][0]))
+        (_, o1, o2), s_o = A.lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **kw)
+        assert score == pytest.approx(s_o, abs=1e-4)
+        assert np.abs(r1 - o1).max() < 1e-2 * np.abs(o1).max() and np.abs(r2 - o2).max() < 1e-2 * np.abs(o2).max()
+    # another seed, another split
+    np.random.seed(12345)
+    (_, q1, _), _ = lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **kw)
+    assert np.abs(q1 - g["seed0_rec1"]).max() > 1e-3 * np.abs(g["seed0_rec1"]).max()

@@ -123,8 +123,6 @@ def test_batch_rejects_what_it_does_not_do():
         PathABatch(img, [ok, lin])
     with pytest.raises(ValueError):
         PathABatch(img, [ok, other_box])
-    with pytest.raises(NotImplementedError):
-        lsq_reconstruct_batch(img, 1.0, [(29.0, 2.0, 1)], fsc_test=1, reconstruct_diameter_3d_pixel=12, reconstruct_length_3d_pixel=4)
 
 
 def test_device_symmetry_pairs_equal_the_sequential_rule(golden_dir, monkeypatch):
