@@ -73,7 +73,7 @@ def test_simulate_reference_error_behaviour():
     with pytest.raises(AssertionError):  # utils.py:88
         H.simulate_helical_projection(1, 30, 5, 1, 64, 3, 0, 0, 32, 32, 2.0)
     with pytest.raises(ValueError):      # the device lattice takes up to 64 atoms per asymmetric unit
-        H.simulate_helical_projection(40, 30, 5, 2, 40, 3, 1, 0.9, 32, 32, 2.0)
+        H.simulate_helical_projection(40, 30, 5, 2, 300, 3, 1, 0.9, 128, 128, 4.0)
 
 
 def test_simulate_with_a_random_polymer_replays_the_reference(golden_dir):
