@@ -170,3 +170,33 @@ def test_full_load_is_reproducible():
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
     assert int(np.argmax(a[1])) in range(k // 2 - 4, k // 2 + 4)       # the truth (29 degrees) is in the middle of the list
+
+
+def test_device_row_enumeration_equals_the_host_one(golden_dir, monkeypatch):
+    """Which rays exist, their order, b and the pixel ids: enumerated on the device from per-slice counts (no per-ray data
+    over PCIe) against the host loop that the half-set batches still use — same tables, and bit-identical solves (the
+    device order of the rows is the same stable slice-major sort), on the sliced path and, with tilt / psi, the general one."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    img = np.ascontiguousarray(g["helix_image"], dtype=np.float32)
+    for tilt, psi, dy in ((0.0, 0.0, 0.0), (0.0, 0.0, 0.75), (3.0, -2.0, 0.5)):
+        specs = [(29.0, 2.0, 1, 700), (31.0, 2.5, 1, 2000), (58.0, 4.0, 2, 1500), (-29.0, 2.0, 1, 300), (27.5, 0.7, 3, 4000)]
+        params = [hh_pa_params(1.0, tw, rs, cs, tilt, psi, dy, 20, 32, 20, 0, 6, want, want, 0, 0, 0) for tw, rs, cs, want in specs]
+        out = {}
+        for mode in ("device", "host"):
+            if mode == "host":
+                monkeypatch.setenv("HH_PAB_HOST_ROWS", "1")
+            else:
+                monkeypatch.delenv("HH_PAB_HOST_ROWS", raising=False)
+            with PathABatch(img, params) as B:
+                rhs = [B.rhs(c) for c in range(len(specs))]
+                x, scores, info = B.solve(np.ones(len(specs), dtype=np.int32), 0)
+                out[mode] = (B.m_data.copy(), B.n_ops.copy(), rhs, x, scores, info)
+        d, h = out["device"], out["host"]
+        np.testing.assert_array_equal(d[0], h[0])
+        np.testing.assert_array_equal(d[1], h[1])
+        for (bd, pd), (bh, ph) in zip(d[2], h[2]):
+            np.testing.assert_array_equal(bd, bh)
+            np.testing.assert_array_equal(pd, ph)
+        np.testing.assert_array_equal(d[3], h[3])
+        np.testing.assert_array_equal(d[4], h[4])
+        np.testing.assert_array_equal(d[5], h[5])
