@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""One batch of K Path-A candidates (tools/path_a_bench.py's 64 x 128 case) for rocprofv3: `--kernel-trace --stats`."""
+"""lsq_reconstruct_batch over N candidates (tools/path_a_bench.py's 64 x 128 case) for rocprofv3 `--kernel-trace --stats`:
+argv = [candidates, group size, streams]."""
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from tools.path_a_bench import batch_run, test_image  # noqa: E402
+from helicon_amd.solver import lsq_reconstruct_batch  # noqa: E402
+from tools.path_a_bench import KW, test_image  # noqa: E402
 
 if __name__ == "__main__":
-    k = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    r = batch_run(test_image(), k, repeat=1)
-    print({key: r[key] for key in ("k", "setup_s", "solve_s", "lsmr_iterations", "launches", "host_syncs", "lsmr_iterations_queued")})
+    total = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    streams = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    img = test_image()
+    tw = np.linspace(27.0, 31.0, total)
+    lsq_reconstruct_batch(img, 1.0, [(float(t), 4.0, 1) for t in tw[:: max(1, total // 16)]], return_3d=False, **KW)
+    t0 = time.perf_counter()
+    lsq_reconstruct_batch(img, 1.0, [(float(t), 4.0, 1) for t in tw], return_3d=False, batch=batch, streams=streams, **KW)
+    print("seconds", time.perf_counter() - t0)
