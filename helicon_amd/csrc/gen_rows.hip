@@ -1,0 +1,507 @@
+// gen_rows.hip — the general-size sweep's row kernel for nx = R1 * R2 (R1, R2 <= 32): second translation unit of
+// libhelicon_hip.so (declared in gen_rows.h, driven by general_host.inc; k_gen_fused in general_sizes.inc stays the
+// kernel for every other nx).
+//
+// What the reference does for such an image is the same as for any other (utils.py:31-47, 91-106: rfft2 of the
+// simulated projection, log1p|F|, masked Pearson score); the algorithm is general_sizes.inc's — a candidate's row of the
+// column-transformed lattice image H[ky][x] is rebuilt from its run's table slice and its column factors, transformed
+// along x, and the three masked moments of the row go to k_finalize.  What differs is how the row is transformed:
+//
+//   * one wavefront carries RPW = 64 / max(R1, R2) rows at once, each on L = max(R1, R2) adjacent lanes; a workgroup is
+//     four wavefronts (RPB = 4 RPW rows of one ky block);
+//   * step 1: lane j < R2 of a row takes the R1 points x = j + R2 r, does the R1-point transform in registers
+//     (compile-time twiddles, no index arithmetic), multiplies by W_nx^(j k1) (twiddles held in registers for all
+//     candidates) and writes A[j][k1] transposed with an odd stride; step 2: lane k1 < R1 takes A[.][k1], does the
+//     R2-point transform in registers and holds the bins kx = k1 + R1 k2 — whose weights it has kept in registers since
+//     the workgroup started.  The row crosses LDS once between the steps and once after the build, in place, and
+//     because a row never leaves its wavefront the steps need no barrier (LDS instructions of a wavefront execute in
+//     order);
+//   * the candidate's column factors are fetched into registers while the previous candidate is transformed and
+//     parked in the other half of a double LDS buffer: one workgroup barrier per candidate.
+//
+// k_gen_fused needs 877 vector + 132 LDS instructions per (row, candidate) at nx = 400 (four Stockham stages of radix
+// 4 / 5 with run-time index arithmetic, 22 % of the lanes idle); this kernel's counts are in DESIGN.md.
+#include "gen_rows.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+// ---- compile-time twiddles ---------------------------------------------------------------------------------------
+constexpr double GR_PI = 3.14159265358979323846264338327950288;
+
+constexpr double gr_sin_small(double x) {   // |x| <= pi / 4
+  const double x2 = x * x;
+  double term = x, sum = x;
+  for (int i = 1; i < 14; ++i) {
+    term *= -x2 / (double)((2 * i) * (2 * i + 1));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double gr_cos_small(double x) {
+  const double x2 = x * x;
+  double term = 1.0, sum = 1.0;
+  for (int i = 1; i < 14; ++i) {
+    term *= -x2 / (double)((2 * i - 1) * (2 * i));
+    sum += term;
+  }
+  return sum;
+}
+// cos(2 pi a / b) by octant symmetry (exact zeros and ones at the multiples of b / 4)
+constexpr double gr_cos_frac(long long a, long long b) {
+  a = ((a % b) + b) % b;
+  if (2 * a > b) a = b - a;                                   // cos is even about pi
+  if (4 * a > b) {                                            // second quadrant: -cos(pi - t)
+    const long long a2 = b - 2 * a, b2 = 2 * b;               // (1/2 - a/b) = (b - 2a) / (2b) <= 1/4
+    if (8 * a2 > b2) return -gr_sin_small(2.0 * GR_PI * (double)(b2 - 4 * a2) / (double)(4 * b2));
+    return -gr_cos_small(2.0 * GR_PI * (double)a2 / (double)b2);
+  }
+  if (8 * a > b) return gr_sin_small(2.0 * GR_PI * (double)(b - 4 * a) / (double)(4 * b));
+  return gr_cos_small(2.0 * GR_PI * (double)a / (double)b);
+}
+constexpr double gr_sin_frac(long long a, long long b) { return gr_cos_frac(4 * a - b, 4 * b); }   // sin t = cos(t - pi/2)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void gr_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gr_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ float2 gr_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 gr_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 gr_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// v * exp(-2 pi i E / R) for compile-time E, R
+template <int E0, int R>
+__device__ __forceinline__ float2 gr_twiddle(float2 v) {
+  constexpr int E = ((E0 % R) + R) % R;
+  if constexpr (E == 0) {
+    return v;
+  } else if constexpr (4 * E == R) {
+    return make_float2(v.y, -v.x);          // -i
+  } else if constexpr (2 * E == R) {
+    return make_float2(-v.x, -v.y);
+  } else if constexpr (4 * E == 3 * R) {
+    return make_float2(-v.y, v.x);          // +i
+  } else if constexpr (8 * E == R) {
+    constexpr float h = 0.70710678118654752440f;
+    return make_float2((v.x + v.y) * h, (v.y - v.x) * h);
+  } else if constexpr (8 * E == 3 * R) {
+    constexpr float h = 0.70710678118654752440f;
+    return make_float2((v.y - v.x) * h, -(v.x + v.y) * h);
+  } else {
+    constexpr float c = (float)gr_cos_frac(E, R), s = (float)-gr_sin_frac(E, R);   // W = c + i s
+    return make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
+  }
+}
+
+constexpr int gr_first_factor(int r) {
+  if (r <= 5 || r == 8) return r;
+  if (r % 4 == 0) return 4;
+  if (r % 2 == 0) return 2;
+  for (int p = 3; p * p <= r; p += 2)
+    if (r % p == 0) return p;
+  return r;
+}
+
+// ---- in-register transforms ----------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void gr_dft(float2 (&a)[R]);
+
+template <>
+__device__ __forceinline__ void gr_dft<2>(float2 (&a)[2]) {
+  const float2 t = a[0];
+  a[0] = gr_add(t, a[1]);
+  a[1] = gr_sub(t, a[1]);
+}
+template <>
+__device__ __forceinline__ void gr_dft<3>(float2 (&a)[3]) {
+  constexpr float s = 0.86602540378443864676f;
+  const float2 t1 = gr_add(a[1], a[2]), t2 = gr_sub(a[1], a[2]);
+  const float2 m = make_float2(a[0].x - 0.5f * t1.x, a[0].y - 0.5f * t1.y);
+  const float2 r = make_float2(s * t2.y, -s * t2.x);
+  a[0] = gr_add(a[0], t1);
+  a[1] = gr_add(m, r);
+  a[2] = gr_sub(m, r);
+}
+template <>
+__device__ __forceinline__ void gr_dft<4>(float2 (&a)[4]) {
+  const float2 s0 = gr_add(a[0], a[2]), d0 = gr_sub(a[0], a[2]);
+  const float2 s1 = gr_add(a[1], a[3]), t = gr_sub(a[1], a[3]);
+  const float2 d1 = make_float2(t.y, -t.x);
+  a[0] = gr_add(s0, s1);
+  a[2] = gr_sub(s0, s1);
+  a[1] = gr_add(d0, d1);
+  a[3] = gr_sub(d0, d1);
+}
+template <>
+__device__ __forceinline__ void gr_dft<5>(float2 (&a)[5]) {
+  constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const float2 p1 = gr_add(a[1], a[4]), m1 = gr_sub(a[1], a[4]), p2 = gr_add(a[2], a[3]), m2 = gr_sub(a[2], a[3]);
+  const float2 x0 = a[0];
+  const float2 u1 = make_float2(x0.x + c1 * p1.x + c2 * p2.x, x0.y + c1 * p1.y + c2 * p2.y);
+  const float2 u2 = make_float2(x0.x + c2 * p1.x + c1 * p2.x, x0.y + c2 * p1.y + c1 * p2.y);
+  const float2 v1 = make_float2(s1 * m1.y + s2 * m2.y, -(s1 * m1.x + s2 * m2.x));
+  const float2 v2 = make_float2(s2 * m1.y - s1 * m2.y, -(s2 * m1.x - s1 * m2.x));
+  a[0] = make_float2(x0.x + p1.x + p2.x, x0.y + p1.y + p2.y);
+  a[1] = gr_add(u1, v1);
+  a[4] = gr_sub(u1, v1);
+  a[2] = gr_add(u2, v2);
+  a[3] = gr_sub(u2, v2);
+}
+template <>
+__device__ __forceinline__ void gr_dft<8>(float2 (&a)[8]) {
+  constexpr float h = 0.70710678118654752440f;
+  float2 e[4] = {gr_add(a[0], a[4]), gr_add(a[1], a[5]), gr_add(a[2], a[6]), gr_add(a[3], a[7])};
+  const float2 o0 = gr_sub(a[0], a[4]), t1 = gr_sub(a[1], a[5]), t2 = gr_sub(a[2], a[6]), t3 = gr_sub(a[3], a[7]);
+  float2 o[4] = {o0, make_float2((t1.x + t1.y) * h, (t1.y - t1.x) * h), make_float2(t2.y, -t2.x),
+                 make_float2((t3.y - t3.x) * h, -(t3.x + t3.y) * h)};
+  gr_dft<4>(e);
+  gr_dft<4>(o);
+  a[0] = e[0]; a[1] = o[0]; a[2] = e[1]; a[3] = o[1];
+  a[4] = e[2]; a[5] = o[2]; a[6] = e[3]; a[7] = o[3];
+}
+
+// an odd prime p: X[m] = a0 + sum_{r=1}^{(p-1)/2} [ (a_r + a_{p-r}) cos(2 pi r m / p) - i (a_r - a_{p-r}) sin(2 pi r m / p) ]
+template <int P>
+__device__ __forceinline__ void gr_dft_prime(float2 (&a)[P]) {
+  constexpr int H = (P - 1) / 2;
+  float2 sp[H], sm[H];
+  gr_for<0, H>([&](auto rc) {
+    constexpr int r = decltype(rc)::value + 1;
+    sp[r - 1] = gr_add(a[r], a[P - r]);
+    sm[r - 1] = gr_sub(a[r], a[P - r]);
+  });
+  const float2 x0 = a[0];
+  float2 tot = x0;
+  gr_for<0, H>([&](auto rc) { tot = gr_add(tot, sp[decltype(rc)::value]); });
+  a[0] = tot;
+  gr_for<0, H>([&](auto mc) {
+    constexpr int m = decltype(mc)::value + 1;
+    float2 u = x0, v = make_float2(0.f, 0.f);   // u: cosine part, v = sum (a_r - a_{p-r}) sin
+    gr_for<0, H>([&](auto rc) {
+      constexpr int r = decltype(rc)::value + 1;
+      constexpr float c = (float)gr_cos_frac((long long)r * m, P), s = (float)gr_sin_frac((long long)r * m, P);
+      u.x = fmaf(c, sp[r - 1].x, u.x);
+      u.y = fmaf(c, sp[r - 1].y, u.y);
+      v.x = fmaf(s, sm[r - 1].x, v.x);
+      v.y = fmaf(s, sm[r - 1].y, v.y);
+    });
+    // -i v = (v.y, -v.x)
+    a[m] = make_float2(u.x + v.y, u.y - v.x);
+    a[P - m] = make_float2(u.x - v.y, u.y + v.x);
+  });
+}
+
+template <int R>
+__device__ __forceinline__ void gr_dft(float2 (&a)[R]) {
+  constexpr int P = gr_first_factor(R);
+  if constexpr (P == R) {
+    gr_dft_prime<R>(a);
+  } else {
+    // R = P Q, x = q + Q p, k = k1 + P k2:  X[k1 + P k2] = sum_q W_Q^(q k2) [ W_R^(q k1) sum_p W_P^(p k1) a[q + Q p] ]
+    constexpr int Q = R / P;
+    float2 b[R];   // b[k1 * Q + q]
+    gr_for<0, Q>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      float2 t[P];
+      gr_for<0, P>([&](auto pc) { t[decltype(pc)::value] = a[q + Q * decltype(pc)::value]; });
+      gr_dft<P>(t);
+      gr_for<0, P>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value;
+        b[k1 * Q + q] = gr_twiddle<q * k1, R>(t[k1]);
+      });
+    });
+    gr_for<0, P>([&](auto kc) {
+      constexpr int k1 = decltype(kc)::value;
+      float2 t[Q];
+      gr_for<0, Q>([&](auto qc) { t[decltype(qc)::value] = b[k1 * Q + decltype(qc)::value]; });
+      gr_dft<Q>(t);
+      gr_for<0, Q>([&](auto k2c) { a[k1 + P * decltype(k2c)::value] = t[decltype(k2c)::value]; });
+    });
+  }
+}
+
+// ---- shape of one instantiation -------------------------------------------------------------------------------------
+constexpr int GR_WAVES = 4;
+constexpr int GR_THREADS = 64 * GR_WAVES;
+constexpr int GR_KG_PF = 16;     // rows of column factors the register prefetch is sized for (more: k_gen_fused)
+
+constexpr int gr_row_len(int r1, int r2) {
+  const int l = r1 > r2 ? r1 : r2, s = r1 | 1, nx = r1 * r2, nxp = (nx + 3) / 4 * 4;
+  int len = r2 * s > nxp ? r2 * s : nxp;
+  const int want = (l + (l & 1)) % 32;   // rows follow each other in bank space like the lanes that hold them
+  while (len % 32 != want) ++len;
+  return len;
+}
+
+template <int R1, int R2>
+struct GrShape {
+  static constexpr int L = R1 > R2 ? R1 : R2;       // lanes per row
+  static constexpr int RPW = 64 / L;                // rows per wavefront
+  static constexpr int RPB = RPW * GR_WAVES;        // rows per workgroup
+  static constexpr int S = R1 | 1;                  // odd stride of the transposed layout between the steps
+  static constexpr int NX = R1 * R2;
+  static constexpr int NXP = (NX + 3) / 4 * 4;
+  static constexpr int NG = NXP / 4;                // column groups of four
+  static constexpr int CGS = NG + 4;                // ints per candidate in cgs
+  static constexpr int CGSP = (CGS + 3) / 4 * 4;
+  static constexpr int ROWLEN = gr_row_len(R1, R2);
+  static constexpr int PFC = (CGS + GR_THREADS - 1) / GR_THREADS;
+  static constexpr int PF = (GR_KG_PF * NG + GR_THREADS - 1) / GR_THREADS;   // float4 of column factors one thread holds in flight
+  // Rows above ~256 points leave room for two workgroups per CU (LDS), so each wavefront may use 256 registers and keeps
+  // its step-1 twiddles in them; shorter rows fit three workgroups and read the twiddles from an LDS table instead.
+  static constexpr bool TW_REGS = NX > 256;
+  static constexpr int MIN_BLOCKS = NX > 256 ? 2 : 3;
+  static_assert(RPW >= 1 && L <= 64, "radix too large");
+};
+
+__device__ __forceinline__ void gr_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int R1, int R2>
+__global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_gen_rows(GenRowsArgs a) {
+  using C = GrShape<R1, R2>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gr_smem[];
+  float2* const rowsb = reinterpret_cast<float2*>(gr_smem);                          // [RPB][ROWLEN]
+  float2* const gs = rowsb + (size_t)C::RPB * C::ROWLEN;                             // [RPB][rows_lds]
+  float* const egb = reinterpret_cast<float*>(gs + (size_t)C::RPB * a.rows_lds);     // [halves][kg][NXP]
+  int* const cgb = reinterpret_cast<int*>(egb + (size_t)a.halves * a.kg * C::NXP);   // [halves][CGSP]
+  float2* const twl = reinterpret_cast<float2*>(cgb + a.halves * C::CGSP);           // [R1][R2] W_nx^(j k1) (short rows only)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m_raw = lane / C::L, j = lane - m_raw * C::L;
+  const bool lane_ok = m_raw < C::RPW;
+  const int m = lane_ok ? m_raw : C::RPW - 1;
+  const int rib = wave * C::RPW + m;                 // the lane's row inside the workgroup
+  const int row = blockIdx.x * C::RPB + rib;
+  const bool row_ok = lane_ok && row < a.nky;
+  float2* const myrow = rowsb + (size_t)rib * C::ROWLEN;
+  const int run = a.layer_run[blockIdx.y];
+  const int cfirst = a.layer_first[blockIdx.y], nc = a.layer_count[blockIdx.y];
+  const int n_e4 = a.kg * C::NG;
+
+  // the run's table slice for the workgroup's rows
+  {
+    const int rows = (2 * a.run_imax[run] + 1) * a.n_units;
+    const float2* const tab = a.table + (size_t)run * a.cap * a.nky;
+    const int ky0 = blockIdx.x * C::RPB;
+    for (int e = tid; e < a.rows_lds * C::RPB; e += GR_THREADS) {
+      const int cr = e / C::RPB, r = e - cr * C::RPB;
+      gs[(size_t)r * a.rows_lds + cr] = (cr < rows && ky0 + r < a.nky) ? tab[(size_t)cr * a.nky + ky0 + r] : make_float2(0.f, 0.f);
+    }
+  }
+  // step-1 twiddles W_nx^(j k1) and the weights of the bins kx = j + R1 k2 this lane will hold after step 2
+  const int j1 = min(j, R2 - 1), j2 = min(j, R1 - 1);
+  float2 tw1[C::TW_REGS ? R1 : 1];
+  if constexpr (C::TW_REGS) {
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) tw1[k1] = a.tw_nx[j1 * k1];
+  } else {
+    for (int e = tid; e < C::NX; e += GR_THREADS) {
+      const int k1 = e / R2, jj = e - k1 * R2;
+      twl[e] = a.tw_nx[jj * k1];
+    }
+  }
+  float2 wreg[R2];
+#pragma unroll
+  for (int k2 = 0; k2 < R2; ++k2)
+    wreg[k2] = (row_ok && j < R1) ? a.w2[(size_t)row * C::NX + j + R1 * k2] : make_float2(0.f, 0.f);
+
+  // column factors of the first candidate
+  float4 pf[C::PF];
+  int pc[C::PFC];
+#define GR_FETCH(CAND)                                                                                        \
+  {                                                                                                           \
+    const float4* const src_ = reinterpret_cast<const float4*>(a.eg + (size_t)(CAND) * a.kg * C::NXP);        \
+    _Pragma("unroll") for (int i = 0; i < C::PF; ++i)                                                         \
+      pf[i] = tid + GR_THREADS * i < n_e4 ? src_[tid + GR_THREADS * i] : make_float4(0.f, 0.f, 0.f, 0.f);     \
+    _Pragma("unroll") for (int i = 0; i < C::PFC; ++i)                                                        \
+      pc[i] = tid + GR_THREADS * i < C::CGS ? a.cgs[(size_t)(CAND) * C::CGS + tid + GR_THREADS * i] : 0;      \
+  }
+#define GR_PARK(HALF)                                                                                         \
+  {                                                                                                           \
+    float4* const dst_ = reinterpret_cast<float4*>(egb + (size_t)(HALF) * a.kg * C::NXP);                     \
+    _Pragma("unroll") for (int i = 0; i < C::PF; ++i)                                                         \
+      if (tid + GR_THREADS * i < n_e4) dst_[tid + GR_THREADS * i] = pf[i];                                    \
+    _Pragma("unroll") for (int i = 0; i < C::PFC; ++i)                                                        \
+      if (tid + GR_THREADS * i < C::CGS) cgb[(HALF) * C::CGSP + tid + GR_THREADS * i] = pc[i];                \
+  }
+  if (nc > 0) {
+    GR_FETCH(cfirst);
+    GR_PARK(0);
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int cc = 0; cc < nc; ++cc) {
+    const int half = a.halves == 2 ? (cc & 1) : 0;
+    if (cc + 1 < nc) GR_FETCH(cfirst + cc + 1);
+    const float* const eg = egb + (size_t)half * a.kg * C::NXP;
+    const int* const cg = cgb + half * C::CGSP;
+    const int kc = max(0, min(a.kg, cg[C::NG]));
+    // ---- the wavefront's RPW rows of H, four columns per lane and pass, natural order
+    for (int xg = lane; xg < C::NG; xg += 64) {
+      const float2* const g0 = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg];
+      const float* const erow = eg + 4 * xg;
+      float2 p[C::RPW][4];
+#pragma unroll
+      for (int r = 0; r < C::RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[r][q] = make_float2(0.f, 0.f);
+      for (int k = 0; k < kc; ++k) {
+        const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
+#pragma unroll
+        for (int r = 0; r < C::RPW; ++r) {
+          const float2 gk = g0[(size_t)r * a.rows_lds + k];
+          p[r][0].x = fmaf(e4.x, gk.x, p[r][0].x); p[r][0].y = fmaf(e4.x, gk.y, p[r][0].y);
+          p[r][1].x = fmaf(e4.y, gk.x, p[r][1].x); p[r][1].y = fmaf(e4.y, gk.y, p[r][1].y);
+          p[r][2].x = fmaf(e4.z, gk.x, p[r][2].x); p[r][2].y = fmaf(e4.z, gk.y, p[r][2].y);
+          p[r][3].x = fmaf(e4.w, gk.x, p[r][3].x); p[r][3].y = fmaf(e4.w, gk.y, p[r][3].y);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < C::RPW; ++r) {
+        float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
+        dst[0] = make_float4(p[r][0].x, p[r][0].y, p[r][1].x, p[r][1].y);
+        dst[1] = make_float4(p[r][2].x, p[r][2].y, p[r][3].x, p[r][3].y);
+      }
+    }
+    gr_wave_fence();
+    // ---- step 1: R1 points x = j + R2 r per lane
+    {
+      float2 v[R1];
+#pragma unroll
+      for (int r = 0; r < R1; ++r) v[r] = myrow[j1 + R2 * r];
+      gr_dft<R1>(v);
+      gr_wave_fence();   // (program order: every lane's reads above precede the writes below)
+      if (lane_ok && j < R2) {
+        myrow[j * C::S] = v[0];
+#pragma unroll
+        for (int k1 = 1; k1 < R1; ++k1) {
+          float2 t;
+          if constexpr (C::TW_REGS) t = tw1[k1]; else t = twl[k1 * R2 + j1];
+          myrow[j * C::S + k1] = gr_mul(v[k1], t);
+        }
+      }
+    }
+    gr_wave_fence();
+    // ---- step 2: A[.][k1 = j] -> the bins kx = j + R1 k2, and the row's three masked moments
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    {
+      float2 v[R2];
+#pragma unroll
+      for (int r = 0; r < R2; ++r) v[r] = myrow[r * C::S + j2];
+      gr_dft<R2>(v);
+#pragma unroll
+      for (int k2 = 0; k2 < R2; ++k2) {
+        const float av = __builtin_amdgcn_sqrtf(v[k2].x * v[k2].x + v[k2].y * v[k2].y);
+        const float q = a.log_flag ? __log2f(1.0f + av) : av;
+        const float2 w = wreg[k2];
+        s1 = fmaf(w.x, q, s1);
+        s2 = fmaf(w.x * q, q, s2);
+        s3 = fmaf(w.y, q, s3);
+      }
+    }
+    // sum over the row's L lanes (segments of the wavefront): lane j = 0 of each row ends with the total
+#pragma unroll
+    for (int off = 1; off < C::L; off <<= 1) {
+      const float t1 = __shfl_down(s1, off, 64), t2 = __shfl_down(s2, off, 64), t3 = __shfl_down(s3, off, 64);
+      if (j + off < C::L) {
+        s1 += t1;
+        s2 += t2;
+        s3 += t3;
+      }
+    }
+    if (row_ok && j == 0) {
+      double* const o = a.partials + ((size_t)(cfirst + cc) * a.nky + row) * 3;
+      o[0] = s1;
+      o[1] = s2;
+      o[2] = s3;
+    }
+    if (a.halves == 1) __syncthreads();   // one buffer: every wavefront has finished with this candidate's factors
+    if (cc + 1 < nc) GR_PARK(a.halves == 2 ? (half ^ 1) : 0);
+    __syncthreads();   // the next candidate's factors are in place
+  }
+}
+
+#undef GR_FETCH
+#undef GR_PARK
+
+// ---- the instantiated factorisations -----------------------------------------------------------------------------------
+#ifndef GEN_ROWS_PAIRS
+#define GEN_ROWS_PAIRS(X) X(20, 20) X(20, 10) X(20, 15) X(12, 8) X(12, 10) X(10, 10)
+#endif
+
+struct GrEntry {
+  int r1, r2;
+  void (*kernel)(GenRowsArgs);
+  int rpb, row_len, nxp, pf, tw_lds, max_blocks;
+};
+#define GR_ENTRY(A, B) \
+  {A, B, &k_gen_rows<A, B>, GrShape<A, B>::RPB, GrShape<A, B>::ROWLEN, GrShape<A, B>::NXP, GrShape<A, B>::PF, GrShape<A, B>::TW_REGS ? 0 : A * B, GrShape<A, B>::MIN_BLOCKS},
+const GrEntry gr_entries[] = {GEN_ROWS_PAIRS(GR_ENTRY)};
+#undef GR_ENTRY
+
+const GrEntry* gr_find(int r1, int r2) {
+  for (const GrEntry& e : gr_entries)
+    if (e.r1 == r1 && e.r2 == r2) return &e;
+  return nullptr;
+}
+
+size_t gr_lds(const GrEntry& e, int rows_lds, int kg, int halves) {
+  const int cgsp = (e.nxp / 4 + 4 + 3) / 4 * 4;
+  return (size_t)e.rpb * e.row_len * sizeof(float2) + (size_t)e.rpb * rows_lds * sizeof(float2) +
+         (size_t)halves * kg * e.nxp * sizeof(float) + (size_t)halves * cgsp * sizeof(int) + (size_t)e.tw_lds * sizeof(float2);
+}
+
+}  // namespace
+
+bool gen_rows_plan(int nx, int rows_lds, int kg, GenRowsPlan* plan) {
+  *plan = GenRowsPlan{};
+  const GrEntry* best = nullptr;
+  double best_cost = 1e300;
+  for (const GrEntry& e : gr_entries) {
+    if (e.r1 * e.r2 != nx) continue;
+    // vector instructions per row, roughly: both transforms ~ R log2 R per lane, one wavefront pass serves RPW rows
+    auto work = [](int r) { double l = 0; for (int t = r; t > 1; t >>= 1) l += 1; return r * (l + 1.0); };
+    const double cost = (work(e.r1) + work(e.r2)) / (double)(e.rpb / GR_WAVES);
+    if (cost < best_cost) { best_cost = cost; best = &e; }
+  }
+  if (!best) return false;
+  plan->r1 = best->r1;
+  plan->r2 = best->r2;
+  plan->rows_per_block = best->rpb;
+  plan->threads = GR_THREADS;
+  // the column factors are double-buffered (one barrier per candidate) unless that costs a resident workgroup
+  const size_t one = gr_lds(*best, rows_lds, kg, 1), two = gr_lds(*best, rows_lds, kg, 2), cu = 160 * 1024;
+  if (one > cu) return false;
+  plan->halves = (two <= cu && cu / two >= std::min<size_t>(cu / one, (size_t)best->max_blocks)) ? 2 : 1;
+  plan->lds = plan->halves == 2 ? two : one;
+  if ((int64_t)kg * (best->nxp / 4) > (int64_t)best->pf * GR_THREADS) return false;
+  return true;
+}
+
+hipError_t gen_rows_prepare(const GenRowsPlan& plan, int* blocks_per_cu) {
+  const GrEntry* e = gr_find(plan.r1, plan.r2);
+  if (!e) return hipErrorInvalidValue;
+  hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(e->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (rc != hipSuccess) return rc;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, e->kernel, GR_THREADS, plan.lds);
+}
+
+hipError_t gen_rows_launch(const GenRowsPlan& plan, int n_ky_blocks, int layers, hipStream_t stream, const GenRowsArgs& args) {
+  const GrEntry* e = gr_find(plan.r1, plan.r2);
+  if (!e) return hipErrorInvalidValue;
+  GenRowsArgs a = args;
+  a.halves = plan.halves;
+  hipLaunchKernelGGL(e->kernel, dim3(n_ky_blocks, layers), dim3(GR_THREADS), plan.lds, stream, a);
+  return hipGetLastError();
+}

@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/helicon_hip.h"
+#include "gen_rows.h"  // the general-size sweep's two-step row kernel (second translation unit, gen_rows.hip)
 
 // Tuning knobs (compile-time; defaults are the measured best)
 #ifndef HH_ABLATE
