@@ -34,6 +34,17 @@ struct GenRowsPlan {
   size_t lds;             // dynamic LDS bytes for (rows_lds, kg)
 };
 
+// one instantiated kernel (the four parts of gen_rows.hip each hold a share of the list)
+struct GenRowsEntry {
+  int r1, r2;
+  void (*kernel)(GenRowsArgs);
+  int rpb, row_len, nxp, pf, tw_lds, max_blocks;
+};
+HH_HIDDEN const GenRowsEntry* gen_rows_part_0(int* n);
+HH_HIDDEN const GenRowsEntry* gen_rows_part_1(int* n);
+HH_HIDDEN const GenRowsEntry* gen_rows_part_2(int* n);
+HH_HIDDEN const GenRowsEntry* gen_rows_part_3(int* n);
+
 // the factorisation for nx (r1 = 0: none), then the launch shape for a batch's (rows_lds, kg); false when it does not
 // fit (LDS, or more column factors than the register prefetch holds)
 HH_HIDDEN bool gen_rows_plan(int nx, int rows_lds, int kg, GenRowsPlan* plan);

@@ -256,7 +256,10 @@ struct GrShape {
   static constexpr int PF = (GR_KG_PF * NG + GR_THREADS - 1) / GR_THREADS;   // float4 of column factors one thread holds in flight
   // Rows above ~256 points leave room for two workgroups per CU (LDS), so each wavefront may use 256 registers and keeps
   // its step-1 twiddles in them; shorter rows fit three workgroups and read the twiddles from an LDS table instead.
-  static constexpr bool TW_REGS = NX > 256;
+  // (the widest radices leave no registers for either table: twiddles and weights then come from global memory / L1)
+  static constexpr bool TW_REGS = NX > 256 && R1 + R2 <= 48;
+  static constexpr bool TW_LDS = NX <= 256;
+  static constexpr bool W_REGS = R1 + R2 <= 48;
   static constexpr int MIN_BLOCKS = NX > 256 ? 2 : 3;
   static_assert(RPW >= 1 && L <= 64, "radix too large");
 };
@@ -304,16 +307,19 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
   if constexpr (C::TW_REGS) {
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) tw1[k1] = a.tw_nx[j1 * k1];
-  } else {
+  } else if constexpr (C::TW_LDS) {
     for (int e = tid; e < C::NX; e += GR_THREADS) {
       const int k1 = e / R2, jj = e - k1 * R2;
       twl[e] = a.tw_nx[jj * k1];
     }
   }
-  float2 wreg[R2];
+  const bool w_ok = row_ok && j < R1;
+  const float2* const wrow = a.w2 + (size_t)(w_ok ? row : 0) * C::NX + j2;
+  float2 wreg[C::W_REGS ? R2 : 1];
+  if constexpr (C::W_REGS) {
 #pragma unroll
-  for (int k2 = 0; k2 < R2; ++k2)
-    wreg[k2] = (row_ok && j < R1) ? a.w2[(size_t)row * C::NX + j + R1 * k2] : make_float2(0.f, 0.f);
+    for (int k2 = 0; k2 < R2; ++k2) wreg[k2] = w_ok ? wrow[R1 * k2] : make_float2(0.f, 0.f);
+  }
 
   // column factors of the first candidate
   float4 pf[C::PF];
@@ -387,7 +393,9 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
 #pragma unroll
         for (int k1 = 1; k1 < R1; ++k1) {
           float2 t;
-          if constexpr (C::TW_REGS) t = tw1[k1]; else t = twl[k1 * R2 + j1];
+          if constexpr (C::TW_REGS) t = tw1[k1];
+          else if constexpr (C::TW_LDS) t = twl[k1 * R2 + j1];
+          else t = a.tw_nx[j1 * k1];
           myrow[j * C::S + k1] = gr_mul(v[k1], t);
         }
       }
@@ -404,7 +412,9 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
       for (int k2 = 0; k2 < R2; ++k2) {
         const float av = __builtin_amdgcn_sqrtf(v[k2].x * v[k2].x + v[k2].y * v[k2].y);
         const float q = a.log_flag ? __log2f(1.0f + av) : av;
-        const float2 w = wreg[k2];
+        float2 w;
+        if constexpr (C::W_REGS) w = wreg[k2];
+        else w = w_ok ? wrow[R1 * k2] : make_float2(0.f, 0.f);
         s1 = fmaf(w.x, q, s1);
         s2 = fmaf(w.x * q, q, s2);
         s3 = fmaf(w.y, q, s3);
@@ -436,27 +446,71 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
 #undef GR_PARK
 
 // ---- the instantiated factorisations -----------------------------------------------------------------------------------
-#ifndef GEN_ROWS_PAIRS
-#define GEN_ROWS_PAIRS(X) X(20, 20) X(20, 10) X(20, 15) X(12, 8) X(12, 10) X(10, 10)
+// For every nx in 32 ... 1024 that is a product of two 7-smooth numbers <= 32: the pair gen_rows_plan's cost rule picks
+// (R1 >= R2: the wider step runs first, so step 2 and the moments keep all of a row's lanes busy).  The list is dealt to
+// four translation units (-DGEN_ROWS_PART=0..3 of this file, compiled side by side by __graft_entry__.build()); part 0
+// also holds the host entry points.
+#define GEN_ROWS_PAIRS_0(X) X(6, 6) X(8, 5) X(8, 7) X(9, 7) X(9, 9) X(10, 10) X(14, 7) X(14, 9) X(15, 12) \
+  X(16, 8) X(16, 15) X(18, 12) X(18, 15) X(21, 7) X(21, 14) X(21, 15) X(21, 18) X(24, 21) X(25, 15) X(25, 21) \
+  X(25, 25) X(27, 15) X(28, 20) X(28, 24) X(30, 24) X(32, 24) X(32, 27) X(32, 32)
+#define GEN_ROWS_PAIRS_1(X) X(7, 6) X(8, 8) X(9, 5) X(10, 7) X(12, 7) X(12, 9) X(15, 7) X(15, 9) X(16, 10) \
+  X(16, 12) X(16, 14) X(20, 15) X(20, 16) X(20, 18) X(24, 16) X(24, 18) X(25, 5) X(25, 7) X(27, 21) X(27, 25) \
+  X(27, 27) X(28, 16) X(28, 21) X(28, 28) X(30, 15) X(30, 28) X(32, 30)
+#define GEN_ROWS_PAIRS_2(X) X(8, 4) X(8, 6) X(9, 8) X(10, 5) X(10, 9) X(14, 8) X(14, 10) X(14, 12) X(14, 14) \
+  X(15, 5) X(15, 15) X(18, 14) X(18, 18) X(20, 14) X(20, 20) X(21, 9) X(21, 16) X(21, 21) X(24, 20) X(24, 24) \
+  X(25, 24) X(27, 18) X(28, 25) X(30, 21) X(30, 25) X(32, 25) X(32, 28)
+#define GEN_ROWS_PAIRS_3(X) X(7, 5) X(7, 7) X(9, 6) X(10, 6) X(10, 8) X(12, 8) X(12, 10) X(12, 12) X(15, 10) \
+  X(15, 14) X(16, 16) X(18, 9) X(18, 16) X(20, 10) X(21, 20) X(25, 10) X(25, 14) X(25, 20) X(27, 9) X(27, 20) \
+  X(27, 24) X(28, 14) X(28, 27) X(30, 27) X(30, 30) X(32, 16) X(32, 20)
+
+#ifndef GEN_ROWS_PART
+#define GEN_ROWS_PART 0
+#endif
+#if GEN_ROWS_PART == 0
+#define GR_MY_PAIRS GEN_ROWS_PAIRS_0
+#elif GEN_ROWS_PART == 1
+#define GR_MY_PAIRS GEN_ROWS_PAIRS_1
+#elif GEN_ROWS_PART == 2
+#define GR_MY_PAIRS GEN_ROWS_PAIRS_2
+#else
+#define GR_MY_PAIRS GEN_ROWS_PAIRS_3
 #endif
 
-struct GrEntry {
-  int r1, r2;
-  void (*kernel)(GenRowsArgs);
-  int rpb, row_len, nxp, pf, tw_lds, max_blocks;
-};
 #define GR_ENTRY(A, B) \
-  {A, B, &k_gen_rows<A, B>, GrShape<A, B>::RPB, GrShape<A, B>::ROWLEN, GrShape<A, B>::NXP, GrShape<A, B>::PF, GrShape<A, B>::TW_REGS ? 0 : A * B, GrShape<A, B>::MIN_BLOCKS},
-const GrEntry gr_entries[] = {GEN_ROWS_PAIRS(GR_ENTRY)};
+  {A, B, &k_gen_rows<A, B>, GrShape<A, B>::RPB, GrShape<A, B>::ROWLEN, GrShape<A, B>::NXP, GrShape<A, B>::PF, GrShape<A, B>::TW_LDS ? A * B : 0, \
+   GrShape<A, B>::MIN_BLOCKS},
+const GenRowsEntry gr_my_entries[] = {GR_MY_PAIRS(GR_ENTRY)};
 #undef GR_ENTRY
 
-const GrEntry* gr_find(int r1, int r2) {
-  for (const GrEntry& e : gr_entries)
-    if (e.r1 == r1 && e.r2 == r2) return &e;
-  return nullptr;
+}  // namespace
+
+#define GR_PART_FN2(K) gen_rows_part_##K
+#define GR_PART_FN(K) GR_PART_FN2(K)
+const GenRowsEntry* GR_PART_FN(GEN_ROWS_PART)(int* n) {
+  *n = (int)(sizeof(gr_my_entries) / sizeof(gr_my_entries[0]));
+  return gr_my_entries;
 }
 
-size_t gr_lds(const GrEntry& e, int rows_lds, int kg, int halves) {
+#if GEN_ROWS_PART == 0
+namespace {
+
+template <class F>
+void gr_each(F&& f) {
+  const GenRowsEntry* (*const parts[])(int*) = {gen_rows_part_0, gen_rows_part_1, gen_rows_part_2, gen_rows_part_3};
+  for (auto part : parts) {
+    int n = 0;
+    const GenRowsEntry* e = part(&n);
+    for (int i = 0; i < n; ++i) f(e[i]);
+  }
+}
+
+const GenRowsEntry* gr_find(int r1, int r2) {
+  const GenRowsEntry* hit = nullptr;
+  gr_each([&](const GenRowsEntry& e) { if (e.r1 == r1 && e.r2 == r2) hit = &e; });
+  return hit;
+}
+
+size_t gr_lds(const GenRowsEntry& e, int rows_lds, int kg, int halves) {
   const int cgsp = (e.nxp / 4 + 4 + 3) / 4 * 4;
   return (size_t)e.rpb * e.row_len * sizeof(float2) + (size_t)e.rpb * rows_lds * sizeof(float2) +
          (size_t)halves * kg * e.nxp * sizeof(float) + (size_t)halves * cgsp * sizeof(int) + (size_t)e.tw_lds * sizeof(float2);
@@ -466,15 +520,15 @@ size_t gr_lds(const GrEntry& e, int rows_lds, int kg, int halves) {
 
 bool gen_rows_plan(int nx, int rows_lds, int kg, GenRowsPlan* plan) {
   *plan = GenRowsPlan{};
-  const GrEntry* best = nullptr;
+  const GenRowsEntry* best = nullptr;
   double best_cost = 1e300;
-  for (const GrEntry& e : gr_entries) {
-    if (e.r1 * e.r2 != nx) continue;
-    // vector instructions per row, roughly: both transforms ~ R log2 R per lane, one wavefront pass serves RPW rows
+  gr_each([&](const GenRowsEntry& e) {
+    if (e.r1 * e.r2 != nx) return;
+    // vector instructions per row, roughly: both transforms ~ R (1 + log2 R) per lane, one wavefront pass serves RPW rows
     auto work = [](int r) { double l = 0; for (int t = r; t > 1; t >>= 1) l += 1; return r * (l + 1.0); };
     const double cost = (work(e.r1) + work(e.r2)) / (double)(e.rpb / GR_WAVES);
     if (cost < best_cost) { best_cost = cost; best = &e; }
-  }
+  });
   if (!best) return false;
   plan->r1 = best->r1;
   plan->r2 = best->r2;
@@ -490,7 +544,7 @@ bool gen_rows_plan(int nx, int rows_lds, int kg, GenRowsPlan* plan) {
 }
 
 hipError_t gen_rows_prepare(const GenRowsPlan& plan, int* blocks_per_cu) {
-  const GrEntry* e = gr_find(plan.r1, plan.r2);
+  const GenRowsEntry* e = gr_find(plan.r1, plan.r2);
   if (!e) return hipErrorInvalidValue;
   hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(e->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (rc != hipSuccess) return rc;
@@ -498,10 +552,11 @@ hipError_t gen_rows_prepare(const GenRowsPlan& plan, int* blocks_per_cu) {
 }
 
 hipError_t gen_rows_launch(const GenRowsPlan& plan, int n_ky_blocks, int layers, hipStream_t stream, const GenRowsArgs& args) {
-  const GrEntry* e = gr_find(plan.r1, plan.r2);
+  const GenRowsEntry* e = gr_find(plan.r1, plan.r2);
   if (!e) return hipErrorInvalidValue;
   GenRowsArgs a = args;
   a.halves = plan.halves;
   hipLaunchKernelGGL(e->kernel, dim3(n_ky_blocks, layers), dim3(GR_THREADS), plan.lds, stream, a);
   return hipGetLastError();
 }
+#endif  // GEN_ROWS_PART == 0
