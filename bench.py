@@ -464,7 +464,7 @@ def config_legs(args, torch, dev):
             tf = flops * cps / 1e12
             leg["roofline"] = {"bound": "fp32_vector", "achieved": tf, "peak": F32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s",
                                "frac": tf / (F32_VECTOR_PEAK / 1e12), "alg_flop_per_candidate": flops, "traffic": None,
-                               "kernel": "k_fused_pass" if shape == ny == nx and (ny & (ny - 1)) == 0 else "k_gen_fused",
+                               "kernel": "k_fused_pass" if shape == ny == nx and (ny & (ny - 1)) == 0 else "k_gen_rows (nx = R1 R2; gen_rows.hip)",
                                "note": "device time of the whole step (sweep + arg-max + D2H), events on the sweep's stream"}
         else:
             # several segments: the masked spectrum q of every candidate is stored once and read once (K bins x 4 B each way)
