@@ -474,7 +474,7 @@ def config_legs(args, torch, dev):
             leg["scores_per_s"] = cps * segments
             leg["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps / (HBM_PEAK / 1e9),
                                "moved_bytes_per_candidate": moved, "traffic": None,
-                               "kernel": "k_fused_pass<EPI_QSTORE> + k_segment_corr",
+                               "kernel": ("k_fused_pass<EPI_QSTORE>" if shape == ny == nx and (ny & (ny - 1)) == 0 else "k_gen_rows (q store)") + " + k_segment_corr",
                                "note": "q = masked log-spectrum of a candidate, written by the fused pass and read by the "
                                        "segment contraction; device time of the whole step"}
         out[name] = leg
@@ -486,6 +486,7 @@ def config_legs(args, torch, dev):
     sweep_leg("C5_64_segments", 512, 64, sweep_axis(0.02, 4.00, 0.02), sweep_axis(4.25, 5.24, 0.01), 5)
     sweep_leg("general_400", (400, 400), 1, tw[70:170], rs, 3)     # (both windows contain the truth's twist 1.20)
     sweep_leg("general_200", (200, 200), 1, tw[20:220], rs, 3)
+    sweep_leg("general_400_64_segments", (400, 400), 64, tw[70:170], rs, 3)   # 64 class averages of an ordinary box size, one grid
     try:
         out["path_a"] = path_a_leg(dev.index or 0)
     except Exception as ex:   # the leg must not take the headline down with it

@@ -21,6 +21,8 @@ struct GenRowsArgs {
   const float2* w2;       // [nky][nx] {w, w (E - Ebar)}
   const float2* tw_nx;    // [nx] exp(-2 pi i k / nx)
   double* partials;       // [B][nky][3]
+  float* q_out;           // several segments: [B][q_stride] masked q, bin (ky, kx) at ky nx + kx (NULL: one segment)
+  int64_t q_stride;
   int cap, rows_lds, kg, n_units, log_flag;
   int nky, nx, nxp;
   int halves;             // 2: the column factors are double-buffered in LDS (set by gen_rows_launch from the plan)

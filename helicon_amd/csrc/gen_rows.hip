@@ -415,6 +415,9 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
         float2 w;
         if constexpr (C::W_REGS) w = wreg[k2];
         else w = w_ok ? wrow[R1 * k2] : make_float2(0.f, 0.f);
+        // several segments: the masked q goes to HBM for the contraction with every segment's centred spectrum
+        // (k_segment_corr); bins outside the mask carry no weight in any segment
+        if (a.q_out && w_ok) a.q_out[(size_t)(cfirst + cc) * a.q_stride + (size_t)row * C::NX + j + R1 * k2] = w.x > 0.f ? q : 0.f;
         s1 = fmaf(w.x, q, s1);
         s2 = fmaf(w.x * q, q, s2);
         s3 = fmaf(w.y, q, s3);

@@ -3440,6 +3440,7 @@ int64_t hh_memory_bytes(const hh_ctx* c, int64_t out[5]) {
   if (const hh_gen* g = c->gen) {
     part[0] += size_of(g->d_table);
     part[1] += size_of(g->d_eg) + size_of(g->d_cgs);
+    part[3] += size_of(g->d_q) + size_of(g->d_cpart) + size_of(g->d_wec) + size_of(g->d_psum);
     for (const void* p : {(const void*)g->d_tw_nx, (const void*)g->d_tw_ny, (const void*)g->d_w2, (const void*)g->d_runs, (const void*)g->d_run_of,
                           (const void*)g->d_layers, (const void*)g->d_partials, (const void*)g->d_r, (const void*)g->d_f, (const void*)g->d_cent})
       part[4] += size_of(p);

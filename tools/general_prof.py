@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The general-size sweep of bench.py's general_400 / general_200 legs, alone, for rocprofv3 `--kernel-trace --stats`:
-argv = [side (400 | 200 | any) or ny,nx, repetitions]; prints candidates/s of the timed steps."""
+argv = [side (400 | 200 | any) or ny,nx, repetitions, segments]; prints candidates/s of the timed steps."""
 import sys
 import time
 from pathlib import Path
@@ -17,11 +17,13 @@ if __name__ == "__main__":
     shape = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "400").split(",")]
     ny, side = (shape[0], shape[-1])
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    segments = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     dev = torch.device("cuda:0")
     eng = H.SweepEngine((ny, side), device=0)
     eng.set_geometry(apix=1.0, helical_diameter=0.4 * ny, ball_radius=2.0)
     clean = eng.simulate(1.20, 4.75, 1)
-    eng.set_reference((clean + np.random.default_rng(0).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32), None, log=True)
+    imgs = np.stack([(clean + np.random.default_rng(sg).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32) for sg in range(segments)])
+    eng.set_reference(imgs if segments > 1 else imgs[0], None, log=True)
     tw, rs = sweep_axis(0.01, 4.00, 0.01), sweep_axis(4.000, 5.245, 0.005)
     twists = tw[70:170] if side >= 300 else tw[20:220]
     grid = build_grid(twists, rs, (1,), tube_length=float(side))
@@ -33,6 +35,8 @@ if __name__ == "__main__":
         sh.step(results_to_host=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    best = int(sh.best_index()[0])
-    print(f"{ny} x {side}: {len(grid)} candidates, {dt * 1e3:.3f} ms per step = {len(grid) / dt / 1e6:.3f} M candidates/s; "
-          f"best (twist, rise) = ({grid.params[best, 0]:.2f}, {grid.params[best, 1]:.3f})", flush=True)
+    bests = sh.best_index()
+    best = int(bests[0])
+    print(f"{ny} x {side}: {len(grid)} candidates x {segments} segment(s), {dt * 1e3:.3f} ms per step = {len(grid) / dt / 1e6:.3f} M candidates/s; "
+          f"best (twist, rise) = ({grid.params[best, 0]:.2f}, {grid.params[best, 1]:.3f}); segments agreeing with the first: "
+          f"{int(sum(int(b) == best for b in bests))}", flush=True)
