@@ -1957,11 +1957,14 @@ constexpr int SC_LD = SC_KC + 4;     // LDS row stride in floats (16-byte aligne
 
 __global__ __launch_bounds__(256) void k_segment_corr(const float* __restrict__ q /*[Bp][K]*/,
                                                       const float* __restrict__ wec /*[Sp][K]*/, int n_k /*N*/,
-                                                      size_t K, int Bp, int Sp, float* __restrict__ part /*[rows][Bp][Sp]*/) {
+                                                      size_t K, int Bp, int Sp, float* __restrict__ part /*[rows][Bp][Sp]*/,
+                                                      const int* __restrict__ slices /*[gridDim.x] or NULL*/) {
   __shared__ __attribute__((aligned(16))) float sA[256 * SC_LD];
   __shared__ __attribute__((aligned(16))) float sB[64 * SC_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-  const int row = blockIdx.x;                 // spectrum row = K-slice of n_k bins
+  // spectrum row = K-slice of n_k bins; with `slices` only the listed ones (those the mask gives any weight) are
+  // contracted, and part is indexed by the position in the list
+  const int row = slices ? slices[blockIdx.x] : (int)blockIdx.x;
   const int c0 = blockIdx.y * 256, s0 = blockIdx.z * 64;
   const int lr = tid >> 3, lc = (tid & 7) * 4;  // staging: thread covers 16 bytes of rows lr + 32 j
   const int na = min(256, Bp - c0);             // candidate rows that exist (Bp is a multiple of 64)
@@ -2005,7 +2008,7 @@ __global__ __launch_bounds__(256) void k_segment_corr(const float* __restrict__ 
   // D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   const int cw = c0 + wave * 64;
   if (cw >= Bp) return;
-  float* const out = part + (size_t)row * Bp * Sp;
+  float* const out = part + (size_t)blockIdx.x * Bp * Sp;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -2395,6 +2398,9 @@ struct hh_ctx {
   size_t cap_argmax = 0;
   size_t cap_w2 = 0, cap_wec = 0, cap_q = 0, cap_cpart = 0, cap_ref = 0, cap_psum = 0, cap_kb = 0;  // bytes
   int* d_kb_list = nullptr;      // ky blocks (8 rows) the mask touches, ascending; block 0 always
+  int* d_seg_rows = nullptr;     // S > 1: spectrum rows with any weight, ascending (the contraction skips the others)
+  size_t cap_seg_rows = 0;
+  int n_seg_rows = 0;
   int n_kb = 0;
   float2* d_table = nullptr;     // shared-twist first pass: [runs per batch][rows][N/2] column-transform table
   size_t cap_table = 0;          // bytes
@@ -2767,11 +2773,11 @@ int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, bool last, float* d_sc
   } else {
     // several segments: one MFMA contraction of the batch's q against all segments' centred
     // spectra, then Pearson per (segment, candidate)
-    const int rows = c->n / 2 + 1;
-    const size_t K = (size_t)rows * c->n;
+    const int rows = c->n_seg_rows;   // rows the mask gives any weight
+    const size_t K = (size_t)(c->n / 2 + 1) * c->n;
     ProfScope ps(c, 2);
     hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 255) / 256, c->s_pad / 64), dim3(256), 0, c->stream, c->d_q,
-                       c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart);
+                       c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart, c->d_seg_rows);
     const int total = nb * c->n_segments;
     hipLaunchKernelGGL(k_sum_partials, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, c->stream, partials, npart,
                        nb, c->d_psum);
@@ -3403,6 +3409,7 @@ void hh_destroy(hh_ctx* c) {
   (void)hipFree(c->d_cpart);
   (void)hipFree(c->d_ref);
   (void)hipFree(c->d_kb_list);
+  (void)hipFree(c->d_seg_rows);
   (void)hipFree(c->d_table);
   (void)hipFree(c->d_eg);
   (void)hipFree(c->d_cgs);
@@ -3623,6 +3630,15 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   if (rcg) return rcg;
   HH_HIP(c, hipMemcpyAsync(c->d_w2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
   if (multi) {
+    std::vector<int> seg_rows;
+    for (int r = 0; r <= n / 2; ++r) {
+      bool any = false;
+      for (int kx = 0; kx < n && !any; ++kx) any = w[(size_t)r * n + kx] > 0.f;
+      if (any) seg_rows.push_back(r);
+    }
+    if ((rcg = ensure_bytes(c, (void**)&c->d_seg_rows, &c->cap_seg_rows, (size_t)(n / 2 + 1) * sizeof(int)))) return rcg;
+    HH_HIP(c, hipMemcpyAsync(c->d_seg_rows, seg_rows.data(), seg_rows.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->n_seg_rows = (int)seg_rows.size();
     if ((rcg = ensure_bytes(c, (void**)&c->d_wec, &c->cap_wec, wecm.size() * sizeof(float)))) return rcg;
     if ((rcg = ensure_bytes(c, (void**)&c->d_ref, &c->cap_ref, (size_t)n_segments * sizeof(RefConsts)))) return rcg;
     HH_HIP(c, hipMemcpyAsync(c->d_wec, wecm.data(), wecm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configuration C5 (64 segments x 512^2 against one 200 x 100 grid) alone, as bench.py's C5 leg runs it,
-for rocprofv3 or for tuning (HH_SEG_BATCH_RT = candidates per fused launch): argv = [repetitions, segments]."""
+for rocprofv3 or for tuning: argv = [repetitions, segments, outer radius of the mask in bins (default: the whole disc)]."""
 import sys
 import time
 from pathlib import Path
@@ -22,7 +22,8 @@ if __name__ == "__main__":
     clean = eng.simulate(1.20, 4.75, 1)
     imgs = np.stack([(clean + np.random.default_rng(s).normal(0, 0.5 * clean.std(), clean.shape)).astype(np.float32)
                      for s in range(segments)])
-    eng.set_reference(imgs, None, log=True)
+    r_hi = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    eng.set_reference(imgs, H.radial_band_mask(512, 512, 2.0, r_hi) if r_hi else None, log=True)
     twists, rises = sweep_axis(0.02, 4.00, 0.02), sweep_axis(4.25, 5.24, 0.01)
     grid = build_grid(twists, rises, (1,), tube_length=512.0)
     sh = ShardedSweep(eng, grid.params, align=len(rises), device=dev)
