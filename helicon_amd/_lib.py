@@ -101,6 +101,7 @@ EXPORTS = {
     "hh_cross_correlation_f64": (C.c_int, [_ctx, _f64p, _f64p, C.c_int64, _f64p]),
     "hh_cosine_similarity_f64": (C.c_int, [_ctx, _f64p, _f64p, C.c_int64, _f64p]),
     "hh_fused_schedule": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "hh_general_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "hh_affine_transform_2d": (C.c_int, [C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _f32p]),
     "hh_transform_map": (C.c_int, [C.c_int, _f32p, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, _f32p]),

@@ -3459,6 +3459,19 @@ int64_t hh_memory_bytes(const hh_ctx* c, int64_t out[5]) {
 
 // The fused pass's launch plan for `runs` runs of `run_len` candidates, `n_kb` ky blocks and `slots` resident workgroups
 // (pure host arithmetic, no device needed): out = {runs_a, groups_a, cpw_a, groups_b, cpw_b, layers}.
+int hh_general_plan(int nx, int rows_lds, int kg, int64_t out[6]) {
+  if (!out || nx < 1 || rows_lds < 1 || kg < 1 || kg > 32) return HH_ERR_ARG;
+  GenRowsPlan rp{};
+  const bool ok = gen_rows_plan(nx, rows_lds, kg, &rp);
+  out[0] = ok ? rp.r1 : 0;
+  out[1] = ok ? rp.r2 : 0;
+  out[2] = ok ? rp.rows_per_block : 8;
+  out[3] = ok ? rp.threads : GEN_THREADS;
+  out[4] = ok ? rp.halves : 1;
+  out[5] = ok ? (int64_t)rp.lds : 0;
+  return HH_OK;
+}
+
 int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]) {
   if (!out || runs < 1 || run_len < 1 || n_kb < 1 || slots < 1) return HH_ERR_ARG;
   const FusedSchedule fs = fused_schedule(runs, run_len, n_kb, slots);

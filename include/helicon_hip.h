@@ -110,6 +110,12 @@ int64_t hh_memory_bytes(const hh_ctx* ctx, int64_t parts[5]);
  * groups_b, cpw_b, layers}.  Pure host arithmetic (the reference has no counterpart: its pool takes one task per candidate,
  * app.py:2473-2476); exported so the plan can be inspected and tested without a device. */
 int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]);
+/* Which row kernel hh_sweep takes for an image that is not a power-of-two square, and its launch shape: nx = row length
+ * (helical axis), rows_lds = table rows a run keeps in LDS ((2 ceil(nx apix / rise_min) + 1) n_units), kg = table rows
+ * one column group may reach (<= 32).  out = {r1, r2, spectrum rows per workgroup, threads per workgroup, LDS buffers
+ * for the column factors (2 = double-buffered), dynamic LDS bytes}; r1 = r2 = 0 when nx has no pair of 7-smooth factors
+ * <= 32 or the shape does not fit (the Stockham kernel of any radix <= 31 runs then).  Pure host arithmetic, no device. */
+int hh_general_plan(int nx, int rows_lds, int kg, int64_t out[6]);
 /* ctx may be NULL: returns the message of the last failed hh_create on this thread. */
 const char* hh_last_error(const hh_ctx* ctx);
 

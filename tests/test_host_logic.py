@@ -319,6 +319,51 @@ def test_fused_launch_schedule_covers_every_candidate_once():
     assert L.hh_fused_schedule(0, 10, 1, 512, out) != 0 and L.hh_fused_schedule(5, 10, 1, 0, out) != 0
 
 
+def test_general_size_plan_picks_factor_pairs_that_fit():
+    """hh_general_plan (pure host arithmetic): every row length that is a product of two 7-smooth numbers <= 32 gets a
+    pair r1 >= r2 with r1 r2 = nx, whole rows on a wavefront, an LDS size inside the CU's 160 KB — two buffers for the
+    column factors only when that costs no resident workgroup; other lengths fall back to the Stockham kernel."""
+    import ctypes as C
+
+    from helicon_amd import _lib
+
+    L = _lib.lib()
+
+    def plan(nx, rows_lds=101, kg=7):
+        out = (C.c_int64 * 6)()
+        assert L.hh_general_plan(nx, rows_lds, kg, out) == 0
+        return tuple(out)
+
+    def smooth(r):
+        for p in (2, 3, 5, 7):
+            while r % p == 0:
+                r //= p
+        return r == 1
+
+    assert plan(400, 201)[:5] == (20, 20, 12, 256, 1)          # 76 KB with one factor buffer: two workgroups per CU
+    assert plan(200)[:5] == (20, 10, 12, 256, 2)               # short rows: three workgroups either way, double-buffered
+    assert plan(154)[:2] == (0, 0) and plan(2 * 37)[:2] == (0, 0)
+    covered = 0
+    for nx in range(32, 1025):
+        r1, r2, rpb, threads, halves, lds = plan(nx)
+        has_pair = any(nx % b == 0 and b <= nx // b <= 32 and smooth(b) and smooth(nx // b) for b in range(4, 33))
+        assert (r1 > 0) == has_pair, nx
+        if not r1:
+            continue
+        covered += 1
+        assert r1 * r2 == nx and 4 <= r2 <= r1 <= 32 and smooth(r1) and smooth(r2)
+        assert rpb == 4 * (64 // r1) and threads == 256 and halves in (1, 2) and 0 < lds <= 160 * 1024
+        if halves == 2:                                        # the second buffer did not cost a resident workgroup
+            one = lds - (kg_bytes := 7 * ((nx + 3) // 4 * 4) * 4) - ((((nx + 3) // 4) + 4 + 3) // 4 * 4) * 4
+            assert (160 * 1024) // lds >= min((160 * 1024) // one, 2 if nx > 256 else 3), (nx, lds, one, kg_bytes)
+    assert covered >= 100
+    assert plan(400, 4001)[:2] == (0, 0)                       # a table slice that cannot fit LDS: not this kernel
+    assert plan(1024, 101, 32)[:2] == (0, 0)                   # more factor rows than the register prefetch holds
+    out = (C.c_int64 * 6)()
+    assert L.hh_general_plan(0, 1, 1, out) != 0 and L.hh_general_plan(64, 1, 33, out) != 0
+
+
+
 _ORDER_PROBE = r"""
 import sys
 sys.path.insert(0, {root!r})
