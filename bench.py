@@ -533,7 +533,9 @@ def path_a_leg(device, total=1024):
                          "traffic_source": "profiles/r03_path_a_traffic.json: measured / algorithmic bytes per iteration = 1.06",
                          "kernel": "k_pabs_matvec<1> + k_pabs_rmatvec<1> (one LSMR iteration of every candidate of a group)",
                          "note": "wall time of the whole call (set-up, all trust-region steps, host polling) against the "
-                                 "bytes of its LSMR iterations only"}}
+                                 "bytes of its LSMR iterations only.  The product kernels are not bound by these bytes: a 4 x "
+                                 "smaller ray map gave bit-identical results in the same time (DESIGN.md, Path A) - their time is "
+                                 "the latency of a 1024-thread slice workgroup's dependent phases at full occupancy"}}
 
 
 PIPELINES = {
