@@ -1953,7 +1953,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 128-byte line; reading them straight from global put every lane of a load on a different row and
 // thrashed the L1), the next slice's loads fly under the current slice's MFMAs.
 constexpr int SC_KC = 32;            // bins per staged slice
-constexpr int SC_LD = SC_KC + 4;     // LDS row stride in floats (16-byte aligned rows)
+// LDS row stride in floats.  The MFMA operand of lane (i, h) is element [i][kk + h]: 32 rows read at once, so the stride
+// must spread 32 rows over 32 different pairs of banks — 34 does (34 i mod 64 = 2 (17 i mod 32)), 36 = the first
+// 16-byte-aligned choice does not (36 i mod 64 takes 16 values: two lanes per bank, SQ_LDS_BANK_CONFLICT 64 % of the LDS
+// cycles and the matrix pipe 58 % busy).  Rows are 8-byte aligned, so a staged float4 goes in as two float2 (a write
+// group of 16 lanes = two rows, whose bank offsets 0 and 34 mod 32 = 2 interleave).
+constexpr int SC_LD = SC_KC + 2;
 
 __global__ __launch_bounds__(256) void k_segment_corr(const float* __restrict__ q /*[Bp][K]*/,
                                                       const float* __restrict__ wec /*[Sp][K]*/, int n_k /*N*/,
@@ -1985,24 +1990,39 @@ __global__ __launch_bounds__(256) void k_segment_corr(const float* __restrict__ 
   for (int k = 0; k < n_k; k += SC_KC) {
     __syncthreads();  // the previous slice has been consumed
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(sA + (lr + 32 * j) * SC_LD + lc) = ra[j];
+    for (int j = 0; j < 8; ++j) {
+      float2* const d = reinterpret_cast<float2*>(sA + (lr + 32 * j) * SC_LD + lc);
+      d[0] = make_float2(ra[j].x, ra[j].y);
+      d[1] = make_float2(ra[j].z, ra[j].w);
+    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(sB + (lr + 32 * j) * SC_LD + lc) = rb[j];
+    for (int j = 0; j < 2; ++j) {
+      float2* const d = reinterpret_cast<float2*>(sB + (lr + 32 * j) * SC_LD + lc);
+      d[0] = make_float2(rb[j].x, rb[j].y);
+      d[1] = make_float2(rb[j].z, rb[j].w);
+    }
     __syncthreads();
     if (k + SC_KC < n_k) fetch(k + SC_KC);
-    const float* const a0p = sA + (wave * 64 + i) * SC_LD + h;
+    const float* const a0p = sA + (wave * 64 + i) * SC_LD + 2 * h;
     const float* const a1p = a0p + 32 * SC_LD;
-    const float* const b0p = sB + i * SC_LD + h;
+    const float* const b0p = sB + i * SC_LD + 2 * h;
     const float* const b1p = b0p + 32 * SC_LD;
-    // lane (i, h) supplies A[i][kk + h] and B[kk + h][i]: both operands use the same k numbering,
-    // which is all a dot product needs
+    // One 8-byte read feeds two MFMA steps: lane (i, h) supplies bins kk + 2 h (first step) and kk + 2 h + 1 (second) of
+    // row i for A and for B alike — both operands use the same k numbering, which is all a dot product needs.  With the
+    // row stride 34 the 32 lanes of a read group land on 32 different bank pairs (ds_read_b64 banks are mod 64; the
+    // 4-byte reads this replaces bank mod 32 and were two-way conflicts at any even stride).
 #pragma unroll
-    for (int kk = 0; kk < SC_KC; kk += 2) {
-      const float a0 = a0p[kk], a1 = a1p[kk], b0 = b0p[kk], b1 = b1p[kk];
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+    for (int kk = 0; kk < SC_KC; kk += 4) {
+      const float2 a0 = *reinterpret_cast<const float2*>(a0p + kk), a1 = *reinterpret_cast<const float2*>(a1p + kk);
+      const float2 b0 = *reinterpret_cast<const float2*>(b0p + kk), b1 = *reinterpret_cast<const float2*>(b1p + kk);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc11, 0, 0, 0);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc11, 0, 0, 0);
     }
   }
   // D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
