@@ -1142,7 +1142,7 @@ struct SecondArgs {
   const float2* w2;       // [N/2+1][T][8] {w, w*(E-Ebar)} at kx = t + 64 m: a lane's 8 bins are contiguous (EPI_SCORE)
   double* partials;       // [B][NPART][3]: moments per spectrum row (and wavefront of the row)  (EPI_SCORE)
   float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
-  float* q_out;           // [B][N/2+1][N] masked q, natural order (EPI_QSTORE)
+  float* q_out;           // [B][N/2+1][N] masked q, rows lane-major (bin kx = wl + m N/8 at [wl][m]) (EPI_QSTORE)
   const int* kb_list;     // ky blocks to process (ascending); NULL = all N/16 of them
   int n_kb;               // entries of kb_list (or N/16)
   int batch;              // candidates in this launch
@@ -1358,9 +1358,11 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 256 ? KB<N>::WAVES_PER_SIMD :
             n1 += wn[m].x * qn;
             n2 += wn[m].x * qn * qn;
             if constexpr (EPI == EPI_QSTORE) {
+              // (q rows are stored lane-major, bin kx = t + m T at [t][m] like W2: a lane's eight bins are 32 contiguous
+              // bytes; k_segment_corr only needs q and the segments' spectra in the SAME order)
               float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
-              q0row[kx] = w[m].x > 0.f ? q0 : 0.f;
-              q0row[(size_t)(N / 2) * N + kx] = wn[m].x > 0.f ? qn : 0.f;
+              q0row[t * 8 + m] = w[m].x > 0.f ? q0 : 0.f;
+              q0row[(size_t)(N / 2) * N + t * 8 + m] = wn[m].x > 0.f ? qn : 0.f;
             } else {
               a3 += w[m].y * q0;
               n3 += wn[m].y * qn;
@@ -1399,7 +1401,7 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 256 ? KB<N>::WAVES_PER_SIMD :
         s1 += w[m].x * q;
         s2 += w[m].x * q * q;
         if constexpr (EPI == EPI_QSTORE)
-          qrow[t + m * T] = w[m].x > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
+          qrow[t * 8 + m] = w[m].x > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
         else
           s3 += w[m].y * q;
       }
@@ -1862,9 +1864,9 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
           n1 += wnm.x * qn;
           n2 += wnm.x * qn * qn;
           if constexpr (EPI == EPI_QSTORE) {
-            float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
-            q0row[kx] = w[m].x > 0.f ? q0 : 0.f;
-            q0row[(size_t)(N / 2) * N + kx] = wnm.x > 0.f ? qn : 0.f;
+            float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;   // (lane-major rows: kx = wl + m T at [wl][m])
+            q0row[wl * 8 + m] = w[m].x > 0.f ? q0 : 0.f;
+            q0row[(size_t)(N / 2) * N + wl * 8 + m] = wnm.x > 0.f ? qn : 0.f;
           } else {
             a3 += w[m].y * q0;
             n3 += wnm.y * qn;
@@ -1894,7 +1896,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         s1 += w[m].x * q;
         s2 += w[m].x * q * q;
         if constexpr (EPI == EPI_QSTORE)
-          qrow[SPLIT ? 2 * (tf + m * TF) + h : t + m * T] = w[m].x > 0.f ? q : 0.f;
+          qrow[wl * 8 + m] = w[m].x > 0.f ? q : 0.f;   // lane-major: two 16-byte stores per lane and row
         else
           s3 += w[m].y * q;
       }
@@ -2410,7 +2412,7 @@ struct hh_ctx {
   int64_t cap_params = 0, cap_scores = 0;
   double* d_units = nullptr;
   float2* d_w2 = nullptr;        // [N/2+1][N/8][8] (lane-major within a row); with S > 1 only w is used
-  float* d_wec = nullptr;        // S > 1: [Sp][K] w (E_s - Ebar_s), natural bin order, Sp = S rounded up to 64
+  float* d_wec = nullptr;        // S > 1: [Sp][K] w (E_s - Ebar_s), rows in q's lane-major bin order, Sp = S rounded up to 64
   float* d_q = nullptr;          // S > 1: [Bp][K] masked q of one batch, Bp = max_batch rounded up to 64
   float* d_cpart = nullptr;      // S > 1: [N/2+1][Bp][Sp] per-row covariance numerators
   RefConsts* d_ref = nullptr;    // S > 1: [S]
@@ -3649,7 +3651,10 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
         const size_t row = i / n, kx = i % n, tt = kx % (n / 8), mm = kx / (n / 8);
         w2[row * n + tt * 8 + mm] = make_float2(w[i], wec);
       }
-      if (multi) wecm[(size_t)s * nh + i] = wec;
+      if (multi) {   // in q's order: bin kx = wl + m (n / 8) of a row at [wl][m]
+        const size_t row = i / n, kx = i % n;
+        wecm[(size_t)s * nh + row * n + (kx % (n / 8)) * 8 + kx / (n / 8)] = wec;
+      }
       swec += (double)wec;
       var_e += (double)w[i] * dc * dc;
     }
