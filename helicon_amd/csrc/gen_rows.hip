@@ -24,6 +24,7 @@
 #include "gen_rows.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <type_traits>
 
 namespace {
@@ -557,6 +558,11 @@ hipError_t gen_rows_prepare(const GenRowsPlan& plan, int* blocks_per_cu) {
 hipError_t gen_rows_launch(const GenRowsPlan& plan, int n_ky_blocks, int layers, hipStream_t stream, const GenRowsArgs& args) {
   const GenRowsEntry* e = gr_find(plan.r1, plan.r2);
   if (!e) return hipErrorInvalidValue;
+  // the kernel's indexing is compiled for this row length, this padding and this LDS layout: refuse anything else
+  if (args.nx != e->r1 * e->r2 || args.nxp != e->nxp || args.kg < 1 || (int64_t)args.kg * (e->nxp / 4) > (int64_t)e->pf * GR_THREADS ||
+      args.rows_lds < args.kg || plan.lds != gr_lds(*e, args.rows_lds, args.kg, plan.halves) || plan.lds > (size_t)160 * 1024 ||
+      n_ky_blocks != (args.nky + e->rpb - 1) / e->rpb || layers < 1 || layers > 65535 || (args.q_out && args.q_stride < (int64_t)args.nky * args.nx))
+    return hipErrorInvalidValue;
   GenRowsArgs a = args;
   a.halves = plan.halves;
   hipLaunchKernelGGL(e->kernel, dim3(n_ky_blocks, layers), dim3(GR_THREADS), plan.lds, stream, a);
