@@ -229,6 +229,9 @@ __device__ __forceinline__ void gr_dft(float2 (&a)[R]) {
 }
 
 // ---- shape of one instantiation -------------------------------------------------------------------------------------
+#ifndef GR_ABLATE
+#define GR_ABLATE 0   // timing-only builds (tools/variants): 1 no build, 2 no step 1, 4 no step 2, 8 no moments, 16 no reduction
+#endif
 constexpr int GR_WAVES = 4;
 constexpr int GR_THREADS = 64 * GR_WAVES;
 constexpr int GR_KG_PF = 16;     // rows of column factors the register prefetch is sized for (more: k_gen_fused)
@@ -354,32 +357,68 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
     const float* const eg = egb + (size_t)half * a.kg * C::NXP;
     const int* const cg = cgb + half * C::CGSP;
     const int kc = max(0, min(a.kg, cg[C::NG]));
-    // ---- the wavefront's RPW rows of H, four columns per lane and pass, natural order
-    for (int xg = lane; xg < C::NG; xg += 64) {
-      const float2* const g0 = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg];
-      const float* const erow = eg + 4 * xg;
-      float2 p[C::RPW][4];
+    // ---- the wavefront's RPW rows of H, four columns per lane and pass, natural order.  A lane's column groups
+    // (xg = lane, lane + 64, ...) are built together and the operands of table row k + 1 are requested before row k is
+    // used: a loop that waits for its own LDS reads every step was a third of the kernel (timing-only builds without it).
+    if (!(GR_ABLATE & 1)) {
+      constexpr int NP = (C::NG + 63) / 64;           // column groups per lane
+      int xg[NP];
+      const float2* g0[NP];
+      const float* erow[NP];
 #pragma unroll
-      for (int r = 0; r < C::RPW; ++r)
+      for (int u = 0; u < NP; ++u) {
+        xg[u] = min(lane + 64 * u, C::NG - 1);        // (a lane past the row's end repeats the last group and does not write)
+        g0[u] = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg[u]];
+        erow[u] = eg + 4 * xg[u];
+      }
+      float2 p[NP][C::RPW][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p[r][q] = make_float2(0.f, 0.f);
-      for (int k = 0; k < kc; ++k) {
-        const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
+      for (int u = 0; u < NP; ++u)
 #pragma unroll
-        for (int r = 0; r < C::RPW; ++r) {
-          const float2 gk = g0[(size_t)r * a.rows_lds + k];
-          p[r][0].x = fmaf(e4.x, gk.x, p[r][0].x); p[r][0].y = fmaf(e4.x, gk.y, p[r][0].y);
-          p[r][1].x = fmaf(e4.y, gk.x, p[r][1].x); p[r][1].y = fmaf(e4.y, gk.y, p[r][1].y);
-          p[r][2].x = fmaf(e4.z, gk.x, p[r][2].x); p[r][2].y = fmaf(e4.z, gk.y, p[r][2].y);
-          p[r][3].x = fmaf(e4.w, gk.x, p[r][3].x); p[r][3].y = fmaf(e4.w, gk.y, p[r][3].y);
+        for (int r = 0; r < C::RPW; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) p[u][r][q] = make_float2(0.f, 0.f);
+      float4 e4n[NP];
+      float2 gkn[NP][C::RPW];
+      auto load = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          e4n[u] = *reinterpret_cast<const float4*>(erow[u] + (size_t)k * C::NXP);
+#pragma unroll
+          for (int r = 0; r < C::RPW; ++r) gkn[u][r] = g0[u][(size_t)r * a.rows_lds + k];
         }
+      };
+      if (kc > 0) load(0);
+      for (int k = 0; k < kc; ++k) {
+        float4 e4[NP];
+        float2 gk[NP][C::RPW];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          e4[u] = e4n[u];
+#pragma unroll
+          for (int r = 0; r < C::RPW; ++r) gk[u][r] = gkn[u][r];
+        }
+        if (k + 1 < kc) load(k + 1);
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+#pragma unroll
+          for (int r = 0; r < C::RPW; ++r) {
+            p[u][r][0].x = fmaf(e4[u].x, gk[u][r].x, p[u][r][0].x); p[u][r][0].y = fmaf(e4[u].x, gk[u][r].y, p[u][r][0].y);
+            p[u][r][1].x = fmaf(e4[u].y, gk[u][r].x, p[u][r][1].x); p[u][r][1].y = fmaf(e4[u].y, gk[u][r].y, p[u][r][1].y);
+            p[u][r][2].x = fmaf(e4[u].z, gk[u][r].x, p[u][r][2].x); p[u][r][2].y = fmaf(e4[u].z, gk[u][r].y, p[u][r][2].y);
+            p[u][r][3].x = fmaf(e4[u].w, gk[u][r].x, p[u][r][3].x); p[u][r][3].y = fmaf(e4[u].w, gk[u][r].y, p[u][r][3].y);
+          }
       }
 #pragma unroll
-      for (int r = 0; r < C::RPW; ++r) {
-        float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
-        dst[0] = make_float4(p[r][0].x, p[r][0].y, p[r][1].x, p[r][1].y);
-        dst[1] = make_float4(p[r][2].x, p[r][2].y, p[r][3].x, p[r][3].y);
-      }
+      for (int u = 0; u < NP; ++u)
+        if (lane + 64 * u < C::NG) {
+#pragma unroll
+          for (int r = 0; r < C::RPW; ++r) {
+            float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg[u]);
+            dst[0] = make_float4(p[u][r][0].x, p[u][r][0].y, p[u][r][1].x, p[u][r][1].y);
+            dst[1] = make_float4(p[u][r][2].x, p[u][r][2].y, p[u][r][3].x, p[u][r][3].y);
+          }
+        }
     }
     gr_wave_fence();
     // ---- step 1: R1 points x = j + R2 r per lane
@@ -387,7 +426,7 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
       float2 v[R1];
 #pragma unroll
       for (int r = 0; r < R1; ++r) v[r] = myrow[j1 + R2 * r];
-      gr_dft<R1>(v);
+      if (!(GR_ABLATE & 2)) gr_dft<R1>(v);
       gr_wave_fence();   // (program order: every lane's reads above precede the writes below)
       if (lane_ok && j < R2) {
         myrow[j * C::S] = v[0];
@@ -408,11 +447,11 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
       float2 v[R2];
 #pragma unroll
       for (int r = 0; r < R2; ++r) v[r] = myrow[r * C::S + j2];
-      gr_dft<R2>(v);
+      if (!(GR_ABLATE & 4)) gr_dft<R2>(v);
 #pragma unroll
       for (int k2 = 0; k2 < R2; ++k2) {
-        const float av = __builtin_amdgcn_sqrtf(v[k2].x * v[k2].x + v[k2].y * v[k2].y);
-        const float q = a.log_flag ? __log2f(1.0f + av) : av;
+        const float av = (GR_ABLATE & 8) ? v[k2].x + v[k2].y : __builtin_amdgcn_sqrtf(v[k2].x * v[k2].x + v[k2].y * v[k2].y);
+        const float q = (GR_ABLATE & 8) ? av : a.log_flag ? __log2f(1.0f + av) : av;
         float2 w;
         if constexpr (C::W_REGS) w = wreg[k2];
         else w = w_ok ? wrow[R1 * k2] : make_float2(0.f, 0.f);
@@ -424,9 +463,18 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
         s3 = fmaf(w.y, q, s3);
       }
     }
-    // sum over the row's L lanes (segments of the wavefront): lane j = 0 of each row ends with the total
+    // sum over the row's L lanes (segments of the wavefront): lane j = 0 of each row ends with the total.  When L is a
+    // multiple of 4 the rows start on quad boundaries: the first two levels are DPP quad permutes (no LDS queue, no
+    // masks: every lane of a quad ends with the quad's sum), the rest shuffles across quads.
+    constexpr int RED0 = (C::L % 4 == 0) ? 4 : 1;
+    if constexpr (RED0 == 4) {
+#define GR_QUAD_ADD(V, CTRL) V += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, 0xF, 0xF, false))
+      GR_QUAD_ADD(s1, 0xB1); GR_QUAD_ADD(s2, 0xB1); GR_QUAD_ADD(s3, 0xB1);   // quad_perm [1,0,3,2]
+      GR_QUAD_ADD(s1, 0x4E); GR_QUAD_ADD(s2, 0x4E); GR_QUAD_ADD(s3, 0x4E);   // quad_perm [2,3,0,1]
+#undef GR_QUAD_ADD
+    }
 #pragma unroll
-    for (int off = 1; off < C::L; off <<= 1) {
+    for (int off = RED0; off < ((GR_ABLATE & 16) ? 1 : C::L); off <<= 1) {
       const float t1 = __shfl_down(s1, off, 64), t2 = __shfl_down(s2, off, 64), t3 = __shfl_down(s3, off, 64);
       if (j + off < C::L) {
         s1 += t1;
