@@ -357,68 +357,36 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
     const float* const eg = egb + (size_t)half * a.kg * C::NXP;
     const int* const cg = cgb + half * C::CGSP;
     const int kc = max(0, min(a.kg, cg[C::NG]));
-    // ---- the wavefront's RPW rows of H, four columns per lane and pass, natural order.  A lane's column groups
-    // (xg = lane, lane + 64, ...) are built together and the operands of table row k + 1 are requested before row k is
-    // used: a loop that waits for its own LDS reads every step was a third of the kernel (timing-only builds without it).
-    if (!(GR_ABLATE & 1)) {
-      constexpr int NP = (C::NG + 63) / 64;           // column groups per lane
-      int xg[NP];
-      const float2* g0[NP];
-      const float* erow[NP];
+    // ---- the wavefront's RPW rows of H, four columns per lane and pass, natural order
+    // (tried: a lane's column groups built together with the next table row's operands requested ahead — more registers
+    // and moves than the waiting it saves: -2 % at 400, +1 % at 200; the build is its FMAs, 288 of them per wavefront
+    // and candidate at nx = 400)
+    if (!(GR_ABLATE & 1))
+    for (int xg = lane; xg < C::NG; xg += 64) {
+      const float2* const g0 = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg];
+      const float* const erow = eg + 4 * xg;
+      float2 p[C::RPW][4];
 #pragma unroll
-      for (int u = 0; u < NP; ++u) {
-        xg[u] = min(lane + 64 * u, C::NG - 1);        // (a lane past the row's end repeats the last group and does not write)
-        g0[u] = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg[u]];
-        erow[u] = eg + 4 * xg[u];
-      }
-      float2 p[NP][C::RPW][4];
+      for (int r = 0; r < C::RPW; ++r)
 #pragma unroll
-      for (int u = 0; u < NP; ++u)
-#pragma unroll
-        for (int r = 0; r < C::RPW; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) p[u][r][q] = make_float2(0.f, 0.f);
-      float4 e4n[NP];
-      float2 gkn[NP][C::RPW];
-      auto load = [&](int k) {
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-          e4n[u] = *reinterpret_cast<const float4*>(erow[u] + (size_t)k * C::NXP);
-#pragma unroll
-          for (int r = 0; r < C::RPW; ++r) gkn[u][r] = g0[u][(size_t)r * a.rows_lds + k];
-        }
-      };
-      if (kc > 0) load(0);
+        for (int q = 0; q < 4; ++q) p[r][q] = make_float2(0.f, 0.f);
       for (int k = 0; k < kc; ++k) {
-        float4 e4[NP];
-        float2 gk[NP][C::RPW];
+        const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-          e4[u] = e4n[u];
-#pragma unroll
-          for (int r = 0; r < C::RPW; ++r) gk[u][r] = gkn[u][r];
+        for (int r = 0; r < C::RPW; ++r) {
+          const float2 gk = g0[(size_t)r * a.rows_lds + k];
+          p[r][0].x = fmaf(e4.x, gk.x, p[r][0].x); p[r][0].y = fmaf(e4.x, gk.y, p[r][0].y);
+          p[r][1].x = fmaf(e4.y, gk.x, p[r][1].x); p[r][1].y = fmaf(e4.y, gk.y, p[r][1].y);
+          p[r][2].x = fmaf(e4.z, gk.x, p[r][2].x); p[r][2].y = fmaf(e4.z, gk.y, p[r][2].y);
+          p[r][3].x = fmaf(e4.w, gk.x, p[r][3].x); p[r][3].y = fmaf(e4.w, gk.y, p[r][3].y);
         }
-        if (k + 1 < kc) load(k + 1);
-#pragma unroll
-        for (int u = 0; u < NP; ++u)
-#pragma unroll
-          for (int r = 0; r < C::RPW; ++r) {
-            p[u][r][0].x = fmaf(e4[u].x, gk[u][r].x, p[u][r][0].x); p[u][r][0].y = fmaf(e4[u].x, gk[u][r].y, p[u][r][0].y);
-            p[u][r][1].x = fmaf(e4[u].y, gk[u][r].x, p[u][r][1].x); p[u][r][1].y = fmaf(e4[u].y, gk[u][r].y, p[u][r][1].y);
-            p[u][r][2].x = fmaf(e4[u].z, gk[u][r].x, p[u][r][2].x); p[u][r][2].y = fmaf(e4[u].z, gk[u][r].y, p[u][r][2].y);
-            p[u][r][3].x = fmaf(e4[u].w, gk[u][r].x, p[u][r][3].x); p[u][r][3].y = fmaf(e4[u].w, gk[u][r].y, p[u][r][3].y);
-          }
       }
 #pragma unroll
-      for (int u = 0; u < NP; ++u)
-        if (lane + 64 * u < C::NG) {
-#pragma unroll
-          for (int r = 0; r < C::RPW; ++r) {
-            float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg[u]);
-            dst[0] = make_float4(p[u][r][0].x, p[u][r][0].y, p[u][r][1].x, p[u][r][1].y);
-            dst[1] = make_float4(p[u][r][2].x, p[u][r][2].y, p[u][r][3].x, p[u][r][3].y);
-          }
-        }
+      for (int r = 0; r < C::RPW; ++r) {
+        float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
+        dst[0] = make_float4(p[r][0].x, p[r][0].y, p[r][1].x, p[r][1].y);
+        dst[1] = make_float4(p[r][2].x, p[r][2].y, p[r][3].x, p[r][3].y);
+      }
     }
     gr_wave_fence();
     // ---- step 1: R1 points x = j + R2 r per lane
