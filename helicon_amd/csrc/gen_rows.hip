@@ -357,35 +357,68 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
     const float* const eg = egb + (size_t)half * a.kg * C::NXP;
     const int* const cg = cgb + half * C::CGSP;
     const int kc = max(0, min(a.kg, cg[C::NG]));
-    // ---- the wavefront's RPW rows of H, four columns per lane and pass, natural order
+    // ---- the wavefront's RPW rows of H, four columns per lane, natural order
     // (tried: a lane's column groups built together with the next table row's operands requested ahead — more registers
-    // and moves than the waiting it saves: -2 % at 400, +1 % at 200; the build is its FMAs, 288 of them per wavefront
-    // and candidate at nx = 400)
-    if (!(GR_ABLATE & 1))
-    for (int xg = lane; xg < C::NG; xg += 64) {
-      const float2* const g0 = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg];
-      const float* const erow = eg + 4 * xg;
-      float2 p[C::RPW][4];
+    // and moves than the waiting it saves; the build is its FMAs)
+    // Passes of 64 column groups: a lane builds its group for all RPW rows (the factors are read once).  When dealing
+    // the groups of the last, partial pass out as (row, group) items takes fewer item passes than there are rows per
+    // wavefront (36 left-over groups x 3 rows at nx = 400: two item passes of 8 FMAs per table row instead of one
+    // grouped pass of 24 with 28 lanes idle), they are.
+    constexpr int REM0 = C::NG % 64, IPASS = (REM0 * C::RPW + 63) / 64;
+    constexpr bool FLAT = REM0 > 0 && IPASS < C::RPW;
+    constexpr int FULL = FLAT ? C::NG / 64 : (C::NG + 63) / 64, REM = FLAT ? REM0 : 0, ITEMS = REM * C::RPW;
+    if (!(GR_ABLATE & 1)) {
 #pragma unroll
-      for (int r = 0; r < C::RPW; ++r)
+      for (int f = 0; f < FULL; ++f) {
+        const int xg = lane + 64 * f;
+        if (xg >= C::NG) break;   // (the partial pass, when it is kept grouped)
+        const float2* const g0 = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg];
+        const float* const erow = eg + 4 * xg;
+        float2 p[C::RPW][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p[r][q] = make_float2(0.f, 0.f);
-      for (int k = 0; k < kc; ++k) {
-        const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
+        for (int r = 0; r < C::RPW; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) p[r][q] = make_float2(0.f, 0.f);
+        for (int k = 0; k < kc; ++k) {
+          const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
+#pragma unroll
+          for (int r = 0; r < C::RPW; ++r) {
+            const float2 gk = g0[(size_t)r * a.rows_lds + k];
+            p[r][0].x = fmaf(e4.x, gk.x, p[r][0].x); p[r][0].y = fmaf(e4.x, gk.y, p[r][0].y);
+            p[r][1].x = fmaf(e4.y, gk.x, p[r][1].x); p[r][1].y = fmaf(e4.y, gk.y, p[r][1].y);
+            p[r][2].x = fmaf(e4.z, gk.x, p[r][2].x); p[r][2].y = fmaf(e4.z, gk.y, p[r][2].y);
+            p[r][3].x = fmaf(e4.w, gk.x, p[r][3].x); p[r][3].y = fmaf(e4.w, gk.y, p[r][3].y);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < C::RPW; ++r) {
-          const float2 gk = g0[(size_t)r * a.rows_lds + k];
-          p[r][0].x = fmaf(e4.x, gk.x, p[r][0].x); p[r][0].y = fmaf(e4.x, gk.y, p[r][0].y);
-          p[r][1].x = fmaf(e4.y, gk.x, p[r][1].x); p[r][1].y = fmaf(e4.y, gk.y, p[r][1].y);
-          p[r][2].x = fmaf(e4.z, gk.x, p[r][2].x); p[r][2].y = fmaf(e4.z, gk.y, p[r][2].y);
-          p[r][3].x = fmaf(e4.w, gk.x, p[r][3].x); p[r][3].y = fmaf(e4.w, gk.y, p[r][3].y);
+          float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
+          dst[0] = make_float4(p[r][0].x, p[r][0].y, p[r][1].x, p[r][1].y);
+          dst[1] = make_float4(p[r][2].x, p[r][2].y, p[r][3].x, p[r][3].y);
         }
       }
+      if constexpr (REM > 0) {
 #pragma unroll
-      for (int r = 0; r < C::RPW; ++r) {
-        float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
-        dst[0] = make_float4(p[r][0].x, p[r][0].y, p[r][1].x, p[r][1].y);
-        dst[1] = make_float4(p[r][2].x, p[r][2].y, p[r][3].x, p[r][3].y);
+        for (int u = 0; u < IPASS; ++u) {
+          const int it = lane + 64 * u;
+          if (it < ITEMS) {
+            const int r = it / REM, xg = 64 * FULL + (it - r * REM);
+            const float2* const g0 = gs + (size_t)(wave * C::RPW + r) * a.rows_lds + cg[xg];
+            const float* const erow = eg + 4 * xg;
+            float2 p0 = make_float2(0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+            for (int k = 0; k < kc; ++k) {
+              const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
+              const float2 gk = g0[k];
+              p0.x = fmaf(e4.x, gk.x, p0.x); p0.y = fmaf(e4.x, gk.y, p0.y);
+              p1.x = fmaf(e4.y, gk.x, p1.x); p1.y = fmaf(e4.y, gk.y, p1.y);
+              p2.x = fmaf(e4.z, gk.x, p2.x); p2.y = fmaf(e4.z, gk.y, p2.y);
+              p3.x = fmaf(e4.w, gk.x, p3.x); p3.y = fmaf(e4.w, gk.y, p3.y);
+            }
+            float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
+            dst[0] = make_float4(p0.x, p0.y, p1.x, p1.y);
+            dst[1] = make_float4(p2.x, p2.y, p3.x, p3.y);
+          }
+        }
       }
     }
     gr_wave_fence();
