@@ -442,8 +442,8 @@ def _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, recons
 def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degree=0, psi_degree=0, dy_pixel=0,
                           thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                           reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
-                          reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, return_3d=True, device=0,
-                          batch=64, streams=8, stats=None):
+                          reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, interpolation="nn", return_3d=True,
+                          device=0, batch=64, streams=8, stats=None):
     """``lsq_reconstruct`` (solver_linear_regression.py:31-547; nearest-neighbour projector, model "lsq", cosine score)
     for MANY (twist_degree, rise_pixel, csym) candidates of one image: the loop the reference's driver runs as a thread
     pool over ``process_one_task`` (app.py:2473-2476).  ``candidates`` is a sequence of ``(twist, rise, csym)``; the
@@ -454,9 +454,29 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     steps.  Up to ``streams`` groups run at once, each from its own host thread on its own HIP stream, so one group's
     stragglers overlap with the other groups' full launches.  A candidate's result does not depend on how the list is
     cut.  Returns ``[((rec3d, half1, half2), score), ...]`` in the order of ``candidates`` (maps are ``None`` with
-    ``return_3d=False``).  ``stats``, if a dict, receives launch / synchronisation counters."""
+    ``return_3d=False``).  ``stats``, if a dict, receives launch / synchronisation counters.
+
+    ``interpolation="linear"`` (the app's default, app.py:577-585) has no group solver yet: the candidates then go one
+    by one through ``lsq_reconstruct`` (``hh_pa``: products on the device, trust-region glue on the host) from
+    ``streams`` threads — the same results in the same order, at that path's rate."""
     img = np.asarray(projection_image)
     cands = [(float(t), float(r), int(c)) for t, r, c in candidates]
+    if interpolation != "nn":
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(c):
+            maps, score = lsq_reconstruct(img, scale2d_to_3d, c[0], c[1], c[2], tilt_degree, psi_degree, dy_pixel, thresh_fraction,
+                                          positive_constraint, reconstruct_diameter_3d_inner_pixel, reconstruct_diameter_2d_pixel,
+                                          reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel, reconstruct_length_3d_pixel,
+                                          sym_oversample, interpolation, fsc_test, device=device)
+            return (maps if return_3d else (None, None, None)), score
+
+        workers = 1 if fsc_test == 1 else max(1, min(int(streams), len(cands)))   # (fsc_test 1 draws from the global RNG in list order)
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            res = list(pool.map(one, cands))
+        if stats is not None:
+            stats.update(groups=len(cands), launches=0, host_syncs=0, lsmr_iterations_queued=0, self_check_failures=0, info=[])
+        return res
     d2, l2, d3, l3, mask, n3, target = _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel,
                                             reconstruct_diameter_3d_pixel, reconstruct_length_3d_pixel,
                                             reconstruct_diameter_3d_inner_pixel, sym_oversample)

@@ -200,3 +200,18 @@ def test_device_row_enumeration_equals_the_host_one(golden_dir, monkeypatch):
         np.testing.assert_array_equal(d[3], h[3])
         np.testing.assert_array_equal(d[4], h[4])
         np.testing.assert_array_equal(d[5], h[5])
+
+
+def test_batch_call_with_trilinear_interpolation_runs_the_single_candidate_path(golden_dir):
+    """interpolation="linear" (the app's default) through the batch entry point: no group solver yet — the candidates go
+    through lsq_reconstruct from a thread pool, same results in list order."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    s2, rs, cs, kw = _helix_kw(g)
+    cands = [(27.0, rs, cs), (29.0, rs, cs), (31.0, rs, cs)]
+    res = lsq_reconstruct_batch(g["helix_image"], s2, cands, interpolation="linear", streams=3, **kw)
+    for (maps, score), (tw, r, c) in zip(res, cands):
+        (want_map, _, _), want = lsq_reconstruct(g["helix_image"], s2, tw, r, c, interpolation="linear", **kw)
+        assert score == want
+        np.testing.assert_array_equal(maps[0], want_map)
+    none = lsq_reconstruct_batch(g["helix_image"], s2, cands[:1], interpolation="linear", return_3d=False, **kw)
+    assert none[0][0] == (None, None, None) and none[0][1] == res[0][1]
