@@ -486,9 +486,10 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     step = max(1, int(batch) // per)
     if random_split:
         streams = 1                  # the draws follow the order of the list
-    # groups of equal size rather than full groups and a remainder; a short list is still spread over the streams (a
-    # group of a dozen candidates already fills its launches' latency)
-    n_groups = max(1, -(-len(cands) // step), min(int(streams), len(cands) // 12))
+    # groups of equal size rather than full groups and a remainder.  A short list is NOT spread thin over the streams: the
+    # device runs the groups' launches mostly one after the other whatever the stream count (Path A), so 100
+    # candidates take 0.25 s as two groups of 50 and 0.33 s as eight groups of 12
+    n_groups = max(1, -(-len(cands) // step), min(int(streams), len(cands) // 48))
     bounds = [round(k * len(cands) / n_groups) for k in range(n_groups + 1)]
 
     def params_of(tw, rs, cs, mode, half, ids=None):
