@@ -497,7 +497,7 @@ def config_legs(args, torch, dev):
 def path_a_leg(device, total=1024):
     """The reference's shipped scorer (sparse least squares + cosine, solver_linear_regression.py:31-547) batched on the
     device: `total` (twist, rise) candidates of a 64 x 128 image (the size the reference app works at after binning to
-    target_apix2d), groups of 64 on 8 streams, set-up included.  Roofline: HBM; bytes = LSMR iterations x the arrays an
+    target_apix2d), groups of 128 on 8 streams, set-up included.  Roofline: HBM; bytes = LSMR iterations x the arrays an
     iteration must touch (Path A)."""
     import helicon_amd as H
     from helicon_amd.solver import lsq_reconstruct_batch
@@ -513,7 +513,7 @@ def path_a_leg(device, total=1024):
     lsq_reconstruct_batch(image, 1.0, [(t, 4.0, 1) for t in tw[:: total // 16]], **kw)   # warm
     st = {}
     t0 = time.perf_counter()
-    res = lsq_reconstruct_batch(image, 1.0, [(float(t), 4.0, 1) for t in tw], batch=64, streams=8, stats=st, **kw)
+    res = lsq_reconstruct_batch(image, 1.0, [(float(t), 4.0, 1) for t in tw], batch=128, streams=8, stats=st, **kw)
     dt = time.perf_counter() - t0
     info = np.asarray(st["info"])
     iters, first = int(info[:, 3].sum()), int(info[:, 4].sum())

@@ -443,7 +443,7 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                           thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                           reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
                           reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, interpolation="nn", return_3d=True,
-                          device=0, batch=64, streams=8, stats=None):
+                          device=0, batch=128, streams=8, stats=None):
     """``lsq_reconstruct`` (solver_linear_regression.py:31-547; nearest-neighbour projector, model "lsq", cosine score)
     for MANY (twist_degree, rise_pixel, csym) candidates of one image: the loop the reference's driver runs as a thread
     pool over ``process_one_task`` (app.py:2473-2476).  ``candidates`` is a sequence of ``(twist, rise, csym)``; the
