@@ -68,6 +68,7 @@ _f64p = C.POINTER(C.c_double)
 EXPORTS = {
     "hh_abi_version": (C.c_int, []),
     "hh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "hh_selftest_exception": (C.c_int, [C.c_int]),
     "hh_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int]),
     "hh_create2": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int, C.c_int]),
     "hh_destroy": (None, [_ctx]),
@@ -202,12 +203,58 @@ def _bind_hip_runtime() -> None:
                 path = cand
     if path is None:
         return
+    # the preload only helps if the loader will match libhelicon_hip.so's request (DT_NEEDED libamdhip64.so.N) against
+    # this file's SONAME; a wheel that bundles another ROCm major would leave the library to map the system runtime as
+    # well — the two-runtime state this function exists to prevent — so such a candidate is skipped
+    want, have = _needed_hip_soname(lib_path()), _soname(path)
+    if choice in ("auto", "torch") and want and have and want != have:
+        return
     try:
         C.CDLL(str(path), mode=C.RTLD_GLOBAL)
         _runtime = str(path)
     except OSError as e:
         raise HeliconHipError(f"cannot load the HIP runtime {path}: {e} (set HELICON_HIP_RUNTIME=system to use "
                               "the one libhelicon_hip.so was linked against)") from e
+
+
+def _dynamic_strings(path, tag: int):
+    """Strings of the ELF dynamic section entries with the given tag (1 = DT_NEEDED, 14 = DT_SONAME); [] if unreadable."""
+    import struct
+
+    try:
+        data = Path(path).read_bytes()
+        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:   # 64-bit little-endian only
+            return []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        sections = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        out = []
+        for sec in sections:
+            if sec[1] != 6:   # SHT_DYNAMIC
+                continue
+            strtab = sections[sec[6]]
+            for off in range(sec[4], sec[4] + sec[5], 16):
+                t, v = struct.unpack_from("<qQ", data, off)
+                if t == 0:
+                    break
+                if t == tag:
+                    start = strtab[4] + v
+                    out.append(data[start: data.index(b"\0", start)].decode())
+        return out
+    except (OSError, struct.error, ValueError, IndexError):
+        return []
+
+
+def _soname(path):
+    names = _dynamic_strings(path, 14)
+    return names[0] if names else None
+
+
+def _needed_hip_soname(path):
+    for name in _dynamic_strings(path, 1):
+        if name.startswith("libamdhip64"):
+            return name
+    return None
 
 
 def hip_runtime_paths():
@@ -240,6 +287,10 @@ def lib():
         fn.argtypes = args
     if handle.hh_abi_version() != 1:
         raise HeliconHipError(f"{path}: ABI version {handle.hh_abi_version()} != 1")
+    runtimes = {os.path.realpath(p) for p in hip_runtime_paths()}
+    if len(runtimes) > 1:   # two HIP runtimes in one process: the second to initialise finds no device
+        raise HeliconHipError(f"two HIP runtimes are mapped into this process ({sorted(runtimes)}): set HELICON_HIP_RUNTIME=system "
+                              "(or to the runtime's path) so that libhelicon_hip.so and every other extension share one")
     _lib = handle
     return _lib
 

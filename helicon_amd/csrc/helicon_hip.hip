@@ -36,7 +36,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_set>
 #include <utility>
@@ -2469,6 +2472,33 @@ int fail(hh_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
+// Exception barrier of the C ABI ("never exit()").  The host code under the entry points uses
+// std::vector / std::string / std::thread; an exception that left an extern "C" function would end the caller's
+// process in std::terminate (a Python process, through ctypes).  Every entry point with a body of its own is a
+// function-try-block whose handler comes here: the exception in flight is rethrown and sorted into a status code and a
+// message for hh_*_last_error.  `set` is fail / pab_fail / pa_fail bound to the object of the call.
+template <class Set>
+int hh_caught(Set&& set, const char* fn) noexcept {
+  try {
+    try {
+      throw;
+    } catch (const std::bad_alloc&) {
+      return set(HH_ERR_NOMEM, std::string(fn) + ": out of host memory (std::bad_alloc)");
+    } catch (const std::length_error& e) {   // a container asked for more elements than it can address: an absurd count
+      return set(HH_ERR_NOMEM, std::string(fn) + ": " + e.what() + " (std::length_error)");
+    } catch (const std::exception& e) {
+      return set(HH_ERR_INTERNAL, std::string(fn) + ": " + e.what());
+    } catch (...) {
+      return set(HH_ERR_INTERNAL, std::string(fn) + ": unknown C++ exception");
+    }
+  } catch (...) {   // even the message could not be built
+    return HH_ERR_NOMEM;
+  }
+}
+#define HH_CATCH_CTX(c, fn) catch (...) { return hh_caught([&](int code, const std::string& m) { return fail(const_cast<hh_ctx*>(static_cast<const hh_ctx*>(c)), code, m); }, fn); }
+#define HH_CATCH_PAB(p, fn) catch (...) { return hh_caught([&](int code, const std::string& m) { return pab_fail(const_cast<hh_pab*>(static_cast<const hh_pab*>(p)), code, m); }, fn); }
+#define HH_CATCH_PA(p, fn) catch (...) { return hh_caught([&](int code, const std::string& m) { return pa_fail(const_cast<hh_pa*>(static_cast<const hh_pa*>(p)), code, m); }, fn); }
+
 #define HH_HIP(ctx, call)                                                                          \
   do {                                                                                             \
     hipError_t e__ = (call);                                                                       \
@@ -3320,7 +3350,7 @@ extern "C" {
 
 int hh_abi_version(void) { return HH_ABI_VERSION; }
 
-int hh_device_count(int* count) {
+int hh_device_count(int* count) try {
   if (!count) return HH_ERR_ARG;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -3329,7 +3359,24 @@ int hh_device_count(int* count) {
   }
   *count = n;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_device_count")
+
+int hh_selftest_exception(int kind) try {
+  if (kind == 0) {
+    std::vector<double> v;
+    v.resize(v.max_size() + (size_t)1);
+    return (int)v.size();
+  }
+  if (kind == 1) {
+    volatile size_t absurd = (size_t)1 << 62;
+    std::vector<char> v;
+    v.reserve(absurd);   // below max_size(): the allocator itself refuses
+    return (int)v.capacity();
+  }
+  if (kind == 2) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "thread");
+  if (kind == 3) throw 42;
+  return HH_OK;
+} HH_CATCH_CTX(nullptr, "hh_selftest_exception")
 
 int64_t hh_algorithmic_bytes(int n) { return 4LL * n * n + 16LL * n * (n / 2 + 1); }
 
@@ -3337,7 +3384,7 @@ const char* hh_last_error(const hh_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 
 int hh_create(hh_ctx** out, int device, int n, int max_batch) { return hh_create2(out, device, n, n, max_batch); }
 
-int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
+int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) try {
   if (!out) return fail(nullptr, HH_ERR_ARG, "hh_create: out is NULL");
   *out = nullptr;
   const bool general = !(ny == nx && supported_n(ny));
@@ -3369,8 +3416,10 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
   c->nx = nx;
   c->general = general;
   c->max_batch = max_batch;
+  struct Guard { hh_ctx* c; ~Guard() { if (c) hh_destroy(c); } } guard{c};   // an exception on the way releases the half-built context
   auto bail = [&](int code, const std::string& msg) {
     g_create_error = msg;
+    guard.c = nullptr;
     hh_destroy(c);
     return code;
   };
@@ -3388,6 +3437,7 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
     c->max_batch = (int)GEN_BATCH;
     const int rcg = gen_create(c, ny, nx);
     if (rcg) return bail(rcg, c->err);
+    guard.c = nullptr;
     *out = c;
     return HH_OK;
   }
@@ -3405,11 +3455,12 @@ int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch) {
   }
   HH_CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
 #undef HH_CREATE_HIP
+  guard.c = nullptr;
   *out = c;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_create2")
 
-void hh_destroy(hh_ctx* c) {
+void hh_destroy(hh_ctx* c) try {
   if (!c) return;
   (void)hh_comm_destroy(c);
   (void)hipSetDevice(c->device);
@@ -3443,6 +3494,7 @@ void hh_destroy(hh_ctx* c) {
   gen_free(c);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+} catch (...) {
 }
 
 int hh_max_batch(const hh_ctx* c) { return c ? c->max_batch : HH_ERR_ARG; }
@@ -3450,7 +3502,7 @@ int hh_max_batch(const hh_ctx* c) { return c ? c->max_batch : HH_ERR_ARG; }
 // Device memory the context holds right now (its buffers grow with the sweeps it has run and are kept until
 // hh_destroy): the sizes the runtime reports for its allocations.  out (may be NULL): {run tables, column factors,
 // two-pass intermediate, several-segment buffers (q + covariance numerators), everything else}.
-int64_t hh_memory_bytes(const hh_ctx* c, int64_t out[5]) {
+int64_t hh_memory_bytes(const hh_ctx* c, int64_t out[5]) try {
   if (!c) return HH_ERR_ARG;
   (void)hipSetDevice(c->device);
   auto size_of = [](const void* p) -> int64_t {
@@ -3477,11 +3529,11 @@ int64_t hh_memory_bytes(const hh_ctx* c, int64_t out[5]) {
   int64_t total = 0;
   for (int k = 0; k < 5; ++k) { total += part[k]; if (out) out[k] = part[k]; }
   return total;
-}
+} HH_CATCH_CTX(c, "hh_memory_bytes")
 
 // The fused pass's launch plan for `runs` runs of `run_len` candidates, `n_kb` ky blocks and `slots` resident workgroups
 // (pure host arithmetic, no device needed): out = {runs_a, groups_a, cpw_a, groups_b, cpw_b, layers}.
-int hh_general_plan(int nx, int rows_lds, int kg, int64_t out[6]) {
+int hh_general_plan(int nx, int rows_lds, int kg, int64_t out[6]) try {
   if (!out || nx < 1 || rows_lds < 1 || kg < 1 || kg > 32) return HH_ERR_ARG;
   GenRowsPlan rp{};
   const bool ok = gen_rows_plan(nx, rows_lds, kg, &rp);
@@ -3492,39 +3544,39 @@ int hh_general_plan(int nx, int rows_lds, int kg, int64_t out[6]) {
   out[4] = ok ? rp.halves : 1;
   out[5] = ok ? (int64_t)rp.lds : 0;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_general_plan")
 
-int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]) {
+int hh_fused_schedule(int64_t runs, int run_len, int n_kb, int slots, int32_t out[6]) try {
   if (!out || runs < 1 || run_len < 1 || n_kb < 1 || slots < 1) return HH_ERR_ARG;
   const FusedSchedule fs = fused_schedule(runs, run_len, n_kb, slots);
   out[0] = fs.runs_a; out[1] = fs.groups_a; out[2] = fs.cpw_a; out[3] = fs.groups_b; out[4] = fs.cpw_b; out[5] = fs.layers;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_fused_schedule")
 
-int hh_set_stream(hh_ctx* c, void* hip_stream) {
+int hh_set_stream(hh_ctx* c, void* hip_stream) try {
   if (!c) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));
   HH_HIP(c, hipStreamSynchronize(c->stream));
   c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL is the device's null stream, a valid choice
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_set_stream")
 
-int hh_use_own_stream(hh_ctx* c) {
+int hh_use_own_stream(hh_ctx* c) try {
   if (!c) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));
   HH_HIP(c, hipStreamSynchronize(c->stream));
   c->stream = c->own_stream;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_use_own_stream")
 
-int hh_synchronize(hh_ctx* c) {
+int hh_synchronize(hh_ctx* c) try {
   if (!c) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));
   HH_HIP(c, hipStreamSynchronize(c->stream));
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_synchronize")
 
-int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
+int hh_set_geometry(hh_ctx* c, const hh_geom* g) try {
   if (!c || !g) return fail(c, HH_ERR_ARG, "hh_set_geometry: NULL argument");
   if (!(g->apix > 0) || !(g->ball_radius > 0) || !(g->helical_diameter >= 0))
     return fail(c, HH_ERR_ARG, "hh_set_geometry: apix and ball_radius must be positive");
@@ -3578,9 +3630,9 @@ int hh_set_geometry(hh_ctx* c, const hh_geom* g) {
   c->geom = d;
   c->have_geom = true;
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_set_geometry")
 
-int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8_t* mask, int log_flag) {
+int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8_t* mask, int log_flag) try {
   if (!c || !images || !mask || n_segments <= 0) return fail(c, HH_ERR_ARG, "hh_set_reference: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
   if (c->general) return gen_set_reference(c, images, n_segments, mask, log_flag);
@@ -3698,46 +3750,46 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   c->n_segments = n_segments;
   c->log_flag = log_flag ? 1 : 0;
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_set_reference")
 
-int hh_sweep_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) {
+int hh_sweep_device(hh_ctx* c, const double* d_params, int64_t g, float* d_scores) try {
   int rc = check_ready(c, true);
   if (rc) return rc;
   if (!d_params || !d_scores || g < 0) return fail(c, HH_ERR_ARG, "hh_sweep_device: bad argument");
   if (g == 0) return HH_OK;
   HH_HIP(c, hipSetDevice(c->device));
   return sweep_on_device(c, d_params, g, d_scores);
-}
+} HH_CATCH_CTX(c, "hh_sweep_device")
 
-int hh_sweep_device_mirrored(hh_ctx* c, const double* d_params, const double* h_params, int64_t g, float* d_scores) {
+int hh_sweep_device_mirrored(hh_ctx* c, const double* d_params, const double* h_params, int64_t g, float* d_scores) try {
   int rc = check_ready(c, true);
   if (rc) return rc;
   if (!d_params || !d_scores || g < 0) return fail(c, HH_ERR_ARG, "hh_sweep_device_mirrored: bad argument");
   if (g == 0) return HH_OK;
   HH_HIP(c, hipSetDevice(c->device));
   return sweep_on_device(c, d_params, g, d_scores, h_params);
-}
+} HH_CATCH_CTX(c, "hh_sweep_device_mirrored")
 
 int hh_sweep_device_strided(hh_ctx* c, const double* d_params, const double* h_params, int64_t g, float* d_scores,
-                            int64_t ld_scores) {
+                            int64_t ld_scores) try {
   int rc = check_ready(c, true);
   if (rc) return rc;
   if (!d_params || !d_scores || g < 0 || ld_scores < g) return fail(c, HH_ERR_ARG, "hh_sweep_device_strided: bad argument");
   if (g == 0) return HH_OK;
   HH_HIP(c, hipSetDevice(c->device));
   return sweep_on_device(c, d_params, g, d_scores, h_params, ld_scores);
-}
+} HH_CATCH_CTX(c, "hh_sweep_device_strided")
 
 int hh_last_first_pass(const hh_ctx* c) { return c ? c->last_first_pass : HH_ERR_ARG; }
 
-int hh_set_table_path(hh_ctx* c, int mode) {
+int hh_set_table_path(hh_ctx* c, int mode) try {
   if (!c) return HH_ERR_ARG;
   c->table_path = mode ? 1 : 0;
   c->fused_path = mode == 1 ? 0 : 1;  // 1: run tables through the two-pass pipeline; 2 (default): fused where it fits
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_set_table_path")
 
-int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
+int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) try {
   int rc = check_ready(c, true);
   if (rc) return rc;
   if (!params || !scores || g < 0) return fail(c, HH_ERR_ARG, "hh_sweep: bad argument");
@@ -3771,9 +3823,9 @@ int hh_sweep(hh_ctx* c, const double* params, int64_t g, float* scores) {
   if (rc) return rc;
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_sweep: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_sweep")
 
-int hh_argmax(const float* scores, int64_t n, int64_t* index) {
+int hh_argmax(const float* scores, int64_t n, int64_t* index) try {
   if (!scores || !index || n <= 0) return HH_ERR_ARG;
   int64_t best = -1;
   for (int64_t i = 0; i < n; ++i) {
@@ -3782,10 +3834,10 @@ int hh_argmax(const float* scores, int64_t n, int64_t* index) {
   }
   *index = best < 0 ? 0 : best;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_argmax")
 
 int hh_argmax_device(hh_ctx* c, const float* d_scores, int64_t n_rows, int64_t n, int64_t ld, int64_t* d_index,
-                     int64_t* h_index) {
+                     int64_t* h_index) try {
   if (!c || !d_scores || (!d_index && !h_index) || n_rows <= 0 || n <= 0 || n_rows > 65535 || (ld != 0 && ld < n))
     return fail(c, HH_ERR_ARG, "hh_argmax_device: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
@@ -3801,7 +3853,7 @@ int hh_argmax_device(hh_ctx* c, const float* d_scores, int64_t n_rows, int64_t n
     HH_HIP(c, hipStreamSynchronize(c->stream));
   }
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_argmax_device")
 
 // ---- the one collective of a multi-GPU sweep, without a host framework: RCCL through dlopen --------------------
 namespace {
@@ -3837,7 +3889,7 @@ Rccl* rccl(std::string& err) {
 }
 }  // namespace
 
-int hh_comm_unique_id(void* id128) {
+int hh_comm_unique_id(void* id128) try {
   if (!id128) return fail(nullptr, HH_ERR_ARG, "hh_comm_unique_id: NULL");
   std::string err;
   Rccl* r = rccl(err);
@@ -3845,9 +3897,9 @@ int hh_comm_unique_id(void* id128) {
   const int rc = r->GetUniqueId(id128);
   if (rc) return fail(nullptr, HH_ERR_HIP, std::string("ncclGetUniqueId: ") + (r->GetErrorString ? r->GetErrorString(rc) : "?"));
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_comm_unique_id")
 
-int hh_comm_init(hh_ctx* c, int rank, int world, const void* id128) {
+int hh_comm_init(hh_ctx* c, int rank, int world, const void* id128) try {
   if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(c, HH_ERR_ARG, "hh_comm_init: bad argument");
   if (c->comm) return fail(c, HH_ERR_STATE, "hh_comm_init: the context already has a communicator");
   std::string err;
@@ -3862,9 +3914,9 @@ int hh_comm_init(hh_ctx* c, int rank, int world, const void* id128) {
     return fail(c, HH_ERR_HIP, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "?"));
   }
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_comm_init")
 
-int hh_allgather(hh_ctx* c, const float* d_send, int64_t count, float* d_recv) {
+int hh_allgather(hh_ctx* c, const float* d_send, int64_t count, float* d_recv) try {
   if (!c || !d_send || !d_recv || count <= 0) return fail(c, HH_ERR_ARG, "hh_allgather: bad argument");
   if (!c->comm) return fail(c, HH_ERR_STATE, "hh_allgather: hh_comm_init has not been called");
   std::string err;
@@ -3874,9 +3926,9 @@ int hh_allgather(hh_ctx* c, const float* d_send, int64_t count, float* d_recv) {
   const int rc = r->AllGather(d_send, d_recv, (size_t)count, /* ncclFloat32 */ 7, c->comm, c->stream);
   if (rc) return fail(c, HH_ERR_HIP, std::string("ncclAllGather: ") + (r->GetErrorString ? r->GetErrorString(rc) : "?"));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_allgather")
 
-int hh_comm_destroy(hh_ctx* c) {
+int hh_comm_destroy(hh_ctx* c) try {
   if (!c) return HH_ERR_ARG;
   if (!c->comm) return HH_OK;
   std::string err;
@@ -3890,9 +3942,9 @@ int hh_comm_destroy(hh_ctx* c) {
   }
   c->comm = nullptr;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_comm_destroy")
 
-int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
+int hh_simulate(hh_ctx* c, const double* params, float* image_out) try {
   int rc = check_ready(c, false);
   if (rc) return rc;
   if (!params || !image_out) return fail(c, HH_ERR_ARG, "hh_simulate: bad argument");
@@ -3923,9 +3975,9 @@ int hh_simulate(hh_ctx* c, const double* params, float* image_out) {
   if (rc) return rc;
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_simulate: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_simulate")
 
-int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_out, float* phase_out) {
+int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_out, float* phase_out) try {
   if (!c || !image || !pwr_out) return fail(c, HH_ERR_ARG, "hh_power_spectrum: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
   if (c->general) return gen_power_spectrum(c, image, log_flag, pwr_out, phase_out);
@@ -3955,10 +4007,10 @@ int hh_power_spectrum(hh_ctx* c, const float* image, int log_flag, float* pwr_ou
   (void)hipFree(d_mm);
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_power_spectrum: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_power_spectrum")
 
 int hh_low_high_pass_filter(hh_ctx* c, const float* image, double low_pass_fraction, double high_pass_fraction,
-                            float* out) {
+                            float* out) try {
   if (!c || !image || !out) return fail(c, HH_ERR_ARG, "hh_low_high_pass_filter: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
   if (c->general) return gen_low_high_pass_filter(c, image, low_pass_fraction, high_pass_fraction, out);
@@ -3983,9 +4035,9 @@ int hh_low_high_pass_filter(hh_ctx* c, const float* image, double low_pass_fract
   HH_HIP(c, hipMemcpyAsync(out, d_out, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HH_HIP(c, hipStreamSynchronize(c->stream));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_low_high_pass_filter")
 
-int hh_threshold_data(hh_ctx* c, const float* data, int64_t n, int use_fraction, double thresh, float* out) {
+int hh_threshold_data(hh_ctx* c, const float* data, int64_t n, int use_fraction, double thresh, float* out) try {
   if (!c || !data || !out || n <= 0) return fail(c, HH_ERR_ARG, "hh_threshold_data: bad argument");
   HH_HIP(c, hipSetDevice(c->device));
   float *d_x = nullptr, *d_y = nullptr;
@@ -4010,12 +4062,12 @@ int hh_threshold_data(hh_ctx* c, const float* data, int64_t n, int use_fraction,
   (void)hipFree(d_mx);
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_threshold_data: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_threshold_data")
 
-int hh_cross_correlation(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return pearson(c, a, b, n, out); }
-int hh_cross_correlation_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return pearson(c, a, b, n, out); }
-int hh_cosine_similarity(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
-int hh_cosine_similarity_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) { return cosine(c, a, b, n, out); }
+int hh_cross_correlation(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) try { return pearson(c, a, b, n, out); } HH_CATCH_CTX(c, "hh_cross_correlation")
+int hh_cross_correlation_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) try { return pearson(c, a, b, n, out); } HH_CATCH_CTX(c, "hh_cross_correlation_f64")
+int hh_cosine_similarity(hh_ctx* c, const float* a, const float* b, int64_t n, double* out) try { return cosine(c, a, b, n, out); } HH_CATCH_CTX(c, "hh_cosine_similarity")
+int hh_cosine_similarity_f64(hh_ctx* c, const double* a, const double* b, int64_t n, double* out) try { return cosine(c, a, b, n, out); } HH_CATCH_CTX(c, "hh_cosine_similarity_f64")
 
 }  // extern "C"
 
@@ -4144,7 +4196,7 @@ __global__ void k_f32_to_f64(const float* __restrict__ in, int64_t n, double* __
 extern "C" {
 
 int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const double matrix[4], const double offset[2],
-                           float* out) {
+                           float* out) try {
   if (!data || !out || !matrix || !offset || ny < 1 || nx < 1)
     return fail(nullptr, HH_ERR_ARG, "hh_affine_transform_2d: bad argument");
   int ndev = 0;
@@ -4166,10 +4218,10 @@ int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const 
   (void)hipFree(d_out);
   if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_affine_transform_2d: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_affine_transform_2d")
 
 int hh_transform_map(int device, const float* data, const int32_t shape[3], double scale, double rot_degree, double tilt_degree,
-                     double psi_degree, double dx, double dy, double dz, float* out) {
+                     double psi_degree, double dx, double dy, double dz, float* out) try {
   if (!data || !out || !shape || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
     return fail(nullptr, HH_ERR_ARG, "hh_transform_map: bad argument");
   int ndev = 0;
@@ -4221,12 +4273,12 @@ int hh_transform_map(int device, const float* data, const int32_t shape[3], doub
   (void)hipFree(d_c);
   if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_transform_map: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_transform_map")
 
 int hh_apply_helical_symmetry(int device, const float* data, const int32_t in_shape[3], double apix,
                               double twist_degree, double rise_angstrom, int csym, double fraction,
                               const int32_t new_size[3], double new_apix, float* out, int32_t out_shape[3],
-                              double* kernel_ms) {
+                              double* kernel_ms) try {
   if (!data || !in_shape || !new_size || !out_shape)
     return fail(nullptr, HH_ERR_ARG, "hh_apply_helical_symmetry: NULL argument");
   const int nz0 = in_shape[0], ny0 = in_shape[1], nx0 = in_shape[2];
@@ -4307,9 +4359,9 @@ int hh_apply_helical_symmetry(int device, const float* data, const int32_t in_sh
   if (e1) (void)hipEventDestroy(e1);
   if (e != hipSuccess) return fail(nullptr, HH_ERR_HIP, std::string("hh_apply_helical_symmetry: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_apply_helical_symmetry")
 
-int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
+int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) try {
   if (!c || bytes <= 0 || (mode != 0 && mode != 1)) return fail(c, HH_ERR_ARG, "hh_calibrate_traffic: bad argument");
   if (c->general) return fail(c, HH_ERR_ARG, "hh_calibrate_traffic: square power-of-two contexts only");
   HH_HIP(c, hipSetDevice(c->device));
@@ -4333,24 +4385,24 @@ int hh_calibrate_traffic(hh_ctx* c, int mode, int64_t bytes) {
   (void)hipFree(sink);
   if (e != hipSuccess) return fail(c, HH_ERR_HIP, std::string("hh_calibrate_traffic: ") + hipGetErrorString(e));
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_calibrate_traffic")
 
-int hh_profile_enable(hh_ctx* c, int on) {
+int hh_profile_enable(hh_ctx* c, int on) try {
   if (!c) return HH_ERR_ARG;
   c->profiling = on > 0 ? on : 0;
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_profile_enable")
 
-int hh_profile_reset(hh_ctx* c) {
+int hh_profile_reset(hh_ctx* c) try {
   if (!c) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));
   HH_HIP(c, hipStreamSynchronize(c->stream));
   c->events_used = 0;
   c->prof_candidates = 0;
   return HH_OK;
-}
+} HH_CATCH_CTX(nullptr, "hh_profile_reset")
 
-int hh_profile_get(hh_ctx* c, hh_profile* out) {
+int hh_profile_get(hh_ctx* c, hh_profile* out) try {
   if (!c || !out) return HH_ERR_ARG;
   HH_HIP(c, hipSetDevice(c->device));
   HH_HIP(c, hipStreamSynchronize(c->stream));
@@ -4368,7 +4420,7 @@ int hh_profile_get(hh_ctx* c, hh_profile* out) {
   p.candidates = c->prof_candidates;
   *out = p;
   return HH_OK;
-}
+} HH_CATCH_CTX(c, "hh_profile_get")
 
 }  // extern "C"
 

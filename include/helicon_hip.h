@@ -21,7 +21,9 @@
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative hh_status otherwise, with a message available from hh_last_error(); nothing calls
- * exit(); no host pointer is retained after a call returns.  Images are C-order float32, ny x nx, with the
+ * exit(), and no C++ exception leaves the library: every entry point with a body of its own is a function-try-block
+ * that turns std::bad_alloc / std::length_error into HH_ERR_NOMEM and anything else into HH_ERR_INTERNAL (message =
+ * what()); no host pointer is retained after a call returns.  Images are C-order float32, ny x nx, with the
  * helical axis along the columns (x); "N" below is the side of a square power-of-two image (the tuned kernels),
  * general sizes: hh_create2.
  * A context is bound to one device and is NOT thread-safe (serialise calls per context).
@@ -44,7 +46,8 @@ typedef enum hh_status {
   HH_ERR_ARG = -1,     /* invalid argument / unsupported size                      */
   HH_ERR_HIP = -2,     /* a HIP runtime call failed                                */
   HH_ERR_STATE = -3,   /* call order (e.g. sweep before set_reference/geometry)    */
-  HH_ERR_NOMEM = -4    /* host or device allocation failed                         */
+  HH_ERR_NOMEM = -4,   /* host or device allocation failed                         */
+  HH_ERR_INTERNAL = -5 /* a C++ exception reached the boundary (message: what())   */
 } hh_status;
 
 typedef struct hh_ctx hh_ctx;
@@ -87,6 +90,13 @@ typedef struct hh_profile {
 
 int hh_abi_version(void);
 int hh_device_count(int* count);
+/* Exercises the exception barrier without a device: raises, inside a guarded entry point, an exception of the kind the
+ * host code under the ABI can meet — kind 0: std::vector::resize with an absurd element count (std::length_error),
+ * 1: an allocation no machine can serve (std::bad_alloc), 2: std::system_error as std::thread raises it, 3: a type
+ * outside std::exception — and returns the status the barrier made of it (HH_ERR_NOMEM, HH_ERR_NOMEM, HH_ERR_INTERNAL,
+ * HH_ERR_INTERNAL; message from hh_last_error(NULL)); any other kind returns HH_OK.  (The reference is Python: an
+ * allocation failure there is a MemoryError the caller can catch, lib/exceptions.py:1-52 — this keeps that property.) */
+int hh_selftest_exception(int kind);
 
 /* device: HIP ordinal; n: image side; max_batch: candidates per launch (0 = default).
  * hh_create2 takes the image's rows and columns (utils.py:31-47 and transforms.py:687-704 accept any (ny, nx); the

@@ -81,6 +81,28 @@ def test_header_symbols_all_exported_and_bound():
     assert L.hh_algorithmic_bytes(1024) == 12599296
 
 
+def test_no_cxx_exception_crosses_the_c_abi():
+    """SURVEY 8(b) "never exit()": the host code under the entry points uses std::vector / std::thread, and round 3 saw a
+    Python process aborted inside hh_pab_create (std::terminate).  Every entry point is now a function-try-block; the
+    self-test raises the exceptions that code can meet INSIDE a guarded entry point and must come back as a status and a
+    message — an absurd element count, an allocation no machine can serve, a thread that cannot start, a foreign type."""
+    L = _lib.lib()
+    want = {0: (-4, b"length_error"), 1: (-4, b"bad_alloc"), 2: (-5, b"Resource temporarily unavailable"), 3: (-5, b"unknown C++ exception")}
+    for kind, (code, text) in want.items():
+        assert L.hh_selftest_exception(kind) == code
+        msg = L.hh_last_error(None)
+        assert msg.startswith(b"hh_selftest_exception: ") and text in msg, msg
+    assert L.hh_selftest_exception(99) == 0
+    # and the source agrees: no entry point with a body of its own is left outside a try block
+    import re
+    csrc = ROOT / "helicon_amd" / "csrc"
+    for f in ("helicon_hip.hip", "fourier_zoom.inc", "path_a_batch.inc", "path_a_host.inc"):
+        text_ = (csrc / f).read_text()
+        for m in re.finditer(r'^(?:extern "C" )?(?:int|int64_t|void) (hh_\w+)\([^;{]*\)\s*(try)?\s*\{(.*)$', text_, re.M):
+            one_liner = m.group(3).rstrip().endswith("}")
+            assert m.group(2) == "try" or one_liner, (f, m.group(1))
+
+
 def test_argmax_rule_is_lowest_index_and_ignores_nan():
     import ctypes as C
     L = _lib.lib()
