@@ -221,6 +221,24 @@ class PathABatch:
             raise _lib.HeliconHipError(f"libhelicon_hip (Path A batch) error {rc}: {msg.decode() if msg else '?'}")
         return x, scores, info
 
+    def matvec(self, c, x):
+        """A_c x through the solve's own product kernels (rows in the reference's order)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(int(self.m_data[c] + self.m_sym[c]), dtype=np.float64)
+        self._check(self._L.hh_pab_matvec(self._h, int(c), _p(x), _p(y)))
+        return y
+
+    def rmatvec(self, c, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        g = np.empty(self.n, dtype=np.float64)
+        self._check(self._L.hh_pab_rmatvec(self._h, int(c), _p(y), _p(g)))
+        return g
+
+    def _check(self, rc):
+        if rc:
+            msg = self._L.hh_pab_last_error(self._h)
+            raise _lib.HeliconHipError(f"libhelicon_hip (Path A batch) error {rc}: {msg.decode() if msg else '?'}")
+
     def counters(self):
         out = (C.c_int64 * 4)()
         self._L.hh_pab_counters(self._h, out)
@@ -461,22 +479,30 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     ``streams`` threads — the same results in the same order, at that path's rate."""
     img = np.asarray(projection_image)
     cands = [(float(t), float(r), int(c)) for t, r, c in candidates]
-    if interpolation != "nn":
+    if interpolation not in ("nn", "linear"):
+        raise ValueError("interpolation must be 'nn' or 'linear'")
+
+    def one_by_one():
+        """The single-candidate path (hh_pa) from a thread pool: trilinear candidates the group solver cannot slice."""
         from concurrent.futures import ThreadPoolExecutor
 
         def one(c):
             maps, score = lsq_reconstruct(img, scale2d_to_3d, c[0], c[1], c[2], tilt_degree, psi_degree, dy_pixel, thresh_fraction,
                                           positive_constraint, reconstruct_diameter_3d_inner_pixel, reconstruct_diameter_2d_pixel,
                                           reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel, reconstruct_length_3d_pixel,
-                                          sym_oversample, interpolation, fsc_test, device=device)
+                                          sym_oversample, interpolation, fsc_test, device=device, _single=True)
             return (maps if return_3d else (None, None, None)), score
 
-        workers = 1 if fsc_test == 1 else max(1, min(int(streams), len(cands)))   # (fsc_test 1 draws from the global RNG in list order)
-        with ThreadPoolExecutor(max_workers=workers) as pool:
+        with ThreadPoolExecutor(max_workers=max(1, min(int(streams), len(cands)))) as pool:
             res = list(pool.map(one, cands))
         if stats is not None:
-            stats.update(groups=len(cands), launches=0, host_syncs=0, lsmr_iterations_queued=0, self_check_failures=0, info=[])
+            stats.update(groups=len(cands), launches=0, host_syncs=0, lsmr_iterations_queued=0, self_check_failures=0, info=[], path="hh_pa")
         return res
+
+    if interpolation == "linear" and (tilt_degree != 0 or psi_degree != 0):
+        if fsc_test == 1:
+            raise NotImplementedError("fsc_test=1 with trilinear interpolation needs tilt = psi = 0 (the group solver)")
+        return one_by_one()
     d2, l2, d3, l3, mask, n3, target = _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel,
                                             reconstruct_diameter_3d_pixel, reconstruct_length_3d_pixel,
                                             reconstruct_diameter_3d_inner_pixel, sym_oversample)
@@ -494,7 +520,8 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
 
     def params_of(tw, rs, cs, mode, half, ids=None):
         q = hh_pa_params(float(scale2d_to_3d), tw, rs, cs, float(tilt_degree), float(psi_degree), float(dy_pixel), d2, l2, d3,
-                         int(reconstruct_diameter_3d_inner_pixel), l3, int(target), int(target), 0, int(mode) if half else 0, half)
+                         int(reconstruct_diameter_3d_inner_pixel), l3, int(target), int(target), 1 if interpolation == "linear" else 0,
+                         int(mode) if half else 0, half)
         if ids is not None:
             q.n_fsc_ids = len(ids)
             q.fsc_ids = ids.ctypes.data_as(C.POINTER(C.c_int32))
@@ -553,13 +580,20 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
             res.append(((maps[0], maps[1], maps[2]), score))
         return res, counters
 
-    if n_groups == 1 or streams <= 1:
-        done = [run_group(g) for g in range(n_groups)]
-    else:
-        from concurrent.futures import ThreadPoolExecutor
+    try:
+        if n_groups == 1 or streams <= 1:
+            done = [run_group(g) for g in range(n_groups)]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
 
-        with ThreadPoolExecutor(max_workers=min(int(streams), n_groups)) as pool:
-            done = list(pool.map(run_group, range(n_groups)))
+            with ThreadPoolExecutor(max_workers=min(int(streams), n_groups)) as pool:
+                done = list(pool.map(run_group, range(n_groups)))
+    except ValueError as e:
+        # a trilinear ray whose samples straddle cell layers (or a cylinder whose two planes do not fit the LDS): the
+        # group solver has no general form of those products, the single-candidate path has
+        if interpolation == "linear" and "not sliceable" in str(e) and fsc_test != 1:
+            return one_by_one()
+        raise
     out = []
     for res, counters in done:
         out.extend(res)
@@ -570,6 +604,7 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
             stats.setdefault("info", []).extend(counters["info"])
     if stats is not None:
         stats["groups"] = n_groups
+        stats["path"] = "hh_pab"
     return out
 
 
@@ -578,7 +613,7 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
                     reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
                     reconstruct_length_3d_pixel=-1, sym_oversample=1, interpolation="nn", fsc_test=0,
                     score_metric="cosine", target_apix2d=5.0, verbose=0, algorithm=dict(model="lsq"),
-                    refine_tilt_psi_dy_range=None, cpu=1, *, device=0):
+                    refine_tilt_psi_dy_range=None, cpu=1, *, device=0, _single=False):
     """solver_linear_regression.py:31-547 for ``interpolation`` "nn" or "linear", ``algorithm["model"] == "lsq"``,
     cosine score: returns ``((rec3d float32 (L3d, D3d, D3d), None, None), score)``, or with ``fsc_test`` 2, 3 or 4 the
     maps of the two pixel halves as well and ``score = s_full / 2 + (s_half1 + s_half2) / 4``.
@@ -590,18 +625,16 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
         raise ValueError("interpolation must be 'nn' or 'linear'")
     if (algorithm or {}).get("model", "lsq") != "lsq":
         raise NotImplementedError("the GPU slice of Path A provides model='lsq' (the scikit-learn models are not deterministic)")
-    if fsc_test == 1 and interpolation != "nn":
-        raise NotImplementedError("fsc_test=1 (the random split of the pixels) is provided with interpolation='nn'")
     if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
         raise NotImplementedError("scores other than cosine need scikit-image")
     if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):
         raise NotImplementedError("tilt / psi / dy refinement is outside this slice")
     img = np.asarray(projection_image)
-    if interpolation == "nn":   # the device-resident solver (a batch of one, or of three with half sets)
+    if interpolation == "nn" or not _single:   # the device-resident solver (a batch of one, or of three with half sets)
         return lsq_reconstruct_batch(img, scale2d_to_3d, [(twist_degree, rise_pixel, csym)], tilt_degree, psi_degree, dy_pixel,
                                      thresh_fraction, positive_constraint, reconstruct_diameter_3d_inner_pixel,
                                      reconstruct_diameter_2d_pixel, reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel,
-                                     reconstruct_length_3d_pixel, sym_oversample, fsc_test, device=device)[0]
+                                     reconstruct_length_3d_pixel, sym_oversample, fsc_test, interpolation=interpolation, device=device)[0]
     d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
     d2 = int(reconstruct_diameter_2d_pixel) if reconstruct_diameter_2d_pixel > 0 else img.shape[0]
     l2 = int(reconstruct_length_2d_pixel) if reconstruct_length_2d_pixel > 0 else img.shape[1]

@@ -348,6 +348,17 @@ int hh_pab_get_pairs(hh_pab* pab, int c, int32_t* out);
  * iterations, LSMR solves, LSMR iterations, of which in the first (unconstrained) solve} or NULL. */
 int hh_pab_solve(hh_pab* pab, const int32_t* positive, const int32_t* clip, double tol, int max_iter, int lsmr_maxiter,
                  float* x_out, double* scores, int32_t* info);
+/* Host-only check of the trilinear products' ray arithmetic (csrc/path_a_linear.inc): the coordinates of every sample of
+ * every ray under every symmetry operation of candidate *params (tilt = psi = 0), once as pa_coords computes them
+ * (back_project_2d_coords_to_3d_coords + solver:1389-1394, 1576-1581) and once with the per-ray part hoisted as the product
+ * kernels do; out = {samples, samples that differ, ray and sample of the first, and — with device >= 0, else -1 — the same
+ * two counts by that device's arithmetic, then the samples whose cell decision differs there, -1}.  device < 0: host only. */
+int hh_pab_check_ray_arithmetic(const hh_pa_params* params, int ny, int nx, int device, int64_t out[8]);
+/* y = A_c x and g = A_c^T y for candidate c through the product kernels the solve uses (A_c = [A_data; A_hsym], the matrix
+ * build_A_data_matrix / build_A_helical_sym_matrix return, solver:1304-1654, 847-1298; rows in the reference's order):
+ * x, g: [unknowns], y: [data rows + symmetry rows], host float64.  For the parity tests; not during a solve. */
+int hh_pab_matvec(hh_pab* pab, int c, const double* x, double* y);
+int hh_pab_rmatvec(hh_pab* pab, int c, const double* y, double* g);
 /* counters of the last hh_pab_solve: {kernel launches, host synchronisations, LSMR iterations queued, failures of the
  * solver's self-check (every workgroup of a launch saw the per-candidate state the previous launch wrote; must be 0)} */
 int hh_pab_counters(const hh_pab* pab, int64_t out[4]);

@@ -296,8 +296,7 @@ def test_transform_map_and_the_tilted_task(golden_dir):
 def test_half_set_solves_reproduce_the_reference(golden_dir):
     """lsq_reconstruct(fsc_test = 2, 3, 4) (solver:175-203, 448-482, 526-547; fixture G11): the data rows of each half of
     the image's pixels are selected inside hh_pa_create (fsc_mode / fsc_half), every half is solved with the same
-    symmetry block; combined score to 1e-4, the three maps to 1 % of their peak.  fsc_test = 1 is the reference's random
-    split and is refused."""
+    symmetry block; combined score to 1e-4, the three maps to 1 % of their peak."""
     g = np.load(golden_dir / "g11_fsc_halves.npz")
     kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=48,
               reconstruct_length_3d_pixel=6, sym_oversample=1, interpolation="nn")
@@ -307,8 +306,13 @@ def test_half_set_solves_reproduce_the_reference(golden_dir):
         for got, name in ((rec, "rec"), (r1, "rec1"), (r2, "rec2")):
             want = g[f"mode{mode}_{name}"]
             assert got.shape == want.shape and np.abs(got - want).max() < 1e-2 * np.abs(want).max(), (mode, name)
-    with pytest.raises(NotImplementedError):     # the random split is provided with the nearest-neighbour projector
-        lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **dict(kw, interpolation="linear"))
+    # the random split (fsc_test = 1) with the trilinear projector: through the group solver since round 4, replayed from the seed
+    runs = []
+    for _ in range(2):
+        np.random.seed(11)
+        runs.append(lsq_reconstruct(g["image"], 1.0, 29.0, 2.0, 1, fsc_test=1, **dict(kw, interpolation="linear")))
+    assert runs[0][1] == runs[1][1] and all(np.array_equal(a, b) for a, b in zip(runs[0][0], runs[1][0]))
+    assert 0.5 < runs[0][1] <= 1.0
     # the halves partition the data rows
     from helicon_amd.solver import PathAProblem
     base = dict(scale2d_to_3d=1.0, twist_degree=29.0, rise_pixel=2.0, csym=1, tilt_degree=0, psi_degree=0, dy_pixel=0,

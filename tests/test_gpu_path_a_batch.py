@@ -202,16 +202,122 @@ def test_device_row_enumeration_equals_the_host_one(golden_dir, monkeypatch):
         np.testing.assert_array_equal(d[5], h[5])
 
 
-def test_batch_call_with_trilinear_interpolation_runs_the_single_candidate_path(golden_dir):
-    """interpolation="linear" (the app's default) through the batch entry point: no group solver yet — the candidates go
-    through lsq_reconstruct from a thread pool, same results in list order."""
+def test_trilinear_batch_against_the_single_candidate_projector_and_the_oracle(golden_dir):
+    """interpolation="linear" (the app's default, app.py:577-585) through the group solver (round 4: slice-major 2 x 2 x 2
+    products, rays recomputed in float64 — csrc/path_a_linear.inc) against (a) the single-candidate hh_pa projector, whose
+    matrices equal the reference's entry for entry (fixture G4b, tests/test_gpu_path_a.py): the products themselves to 1e-12
+    (hh_pab_matvec / hh_pab_rmatvec: the solve's own kernels), UNBOUNDED solves — one LSMR solve each at lsq_linear's loose
+    tolerance, where a norm's last bit can cost or save an iteration: 1e-4 — and (b) the float64 oracle and the reference's own scores (G4b) on the bounded
+    ones at the tolerance that solve allows (2e-3, see test_lsq_reconstruct_trilinear)."""
+    g = np.load(golden_dir / "g4b_path_a_linear.npz")
+    kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=32,
+              reconstruct_length_3d_pixel=6, sym_oversample=1)
+    img = g["helix_image"]
+    cands = [(float(tw), 2.0, 1) for tw in g["helix_twists"]] + [(58.0, 4.0, 2), (-29.0, 2.0, 1), (27.5, 1.7, 1), (31.0, 2.5, 1)]
+    stats = {}
+    rng = np.random.default_rng(5)
+    params = [hh_pa_params(1.0, tw, rs, cs, 0.0, 0.0, 0.0, 20, 32, 20, 0, 6, 960, 960, 1, 0, 0) for tw, rs, cs in cands]
+    with PathABatch(img, params) as B:
+        for c, (tw, rs, cs) in enumerate(cands):
+            with PathAProblem(img, scale2d_to_3d=1.0, twist_degree=tw, rise_pixel=rs, csym=cs, tilt_degree=0, psi_degree=0, dy_pixel=0,
+                              reconstruct_diameter_2d_pixel=20, reconstruct_length_2d_pixel=32, reconstruct_diameter_3d_pixel=20,
+                              reconstruct_diameter_3d_inner_pixel=0, reconstruct_length_3d_pixel=6, min_projection_lines=960,
+                              min_sym_pairs=960, interpolation="linear") as P:
+                assert (B.n, int(B.m_data[c]), int(B.m_sym[c]), int(B.n_ops[c])) == (P.n, P.m_data, P.m_sym, P.n_ops)
+                b, pid = B.rhs(c)
+                np.testing.assert_array_equal(b, P.b_data)
+                np.testing.assert_array_equal(pid, P.b_pid)
+                x, y = rng.normal(size=P.n), rng.normal(size=P.m)
+                np.testing.assert_allclose(B.matvec(c, x), P.matvec(x), rtol=0, atol=1e-12)
+                np.testing.assert_allclose(B.rmatvec(c, y), P.rmatvec(y), rtol=0, atol=1e-12)
+    free = lsq_reconstruct_batch(img, 1.0, cands, positive_constraint=0, interpolation="linear", stats=stats, **kw)
+    assert stats.get("path") != "hh_pa" and stats["self_check_failures"] == 0 and stats["launches"] > 0
+    for (maps, score), (tw, rs, cs) in zip(free, cands):
+        (rec_1, _, _), s_1 = lsq_reconstruct(img, 1.0, tw, rs, cs, positive_constraint=0, interpolation="linear", _single=True, **kw)
+        assert score == pytest.approx(s_1, abs=1e-4), (tw, rs, cs)
+        assert np.abs(maps[0] - rec_1).max() < 1e-2 * np.abs(rec_1).max(), (tw, rs, cs)
+    (rec_o, _, _), s_o = A.lsq_reconstruct(img, 1.0, 29.0, 2.0, 1, positive_constraint=0, interpolation="linear", **kw)
+    assert free[1][1] == pytest.approx(s_o, abs=1e-4)
+    bounded = lsq_reconstruct_batch(img, 1.0, cands[:3], interpolation="linear", **kw)
+    for (maps, score), want, (tw, rs, cs) in zip(bounded, g["helix_scores"], cands):
+        (rec_o, _, _), s_o = A.lsq_reconstruct(img, 1.0, tw, rs, cs, interpolation="linear", **kw)
+        assert score == pytest.approx(s_o, abs=2e-3) and score == pytest.approx(float(want), abs=2e-3), tw
+        assert A.cosine_similarity(maps[0].ravel(), rec_o.ravel()) > 0.995
+    assert int(np.argmax([s for _, s in bounded])) == 1
+
+
+def test_trilinear_batch_composition_runs_and_half_sets(golden_dir):
+    """The trilinear group solver: a candidate's result does not depend on its batch or on the run (bit for bit), the
+    single call is a batch of one, return_3d=False gives the same scores, fsc_test = 2 returns three maps and the
+    combined score of its three solves."""
     g = np.load(golden_dir / "g5_lsq.npz")
     s2, rs, cs, kw = _helix_kw(g)
-    cands = [(27.0, rs, cs), (29.0, rs, cs), (31.0, rs, cs)]
-    res = lsq_reconstruct_batch(g["helix_image"], s2, cands, interpolation="linear", streams=3, **kw)
+    twists = [25.0 + 0.75 * k for k in range(12)]
+    cands = [(t, rs, cs) for t in twists]
+    big = lsq_reconstruct_batch(g["helix_image"], s2, cands, interpolation="linear", **kw)
+    again = lsq_reconstruct_batch(g["helix_image"], s2, cands, interpolation="linear", **kw)
+    split = lsq_reconstruct_batch(g["helix_image"], s2, cands, interpolation="linear", batch=5, streams=3, **kw)
+    none = lsq_reconstruct_batch(g["helix_image"], s2, cands, interpolation="linear", return_3d=False, **kw)
+    for k in range(12):
+        assert big[k][1] == again[k][1] == split[k][1] == none[k][1]
+        np.testing.assert_array_equal(big[k][0][0], again[k][0][0])
+        np.testing.assert_array_equal(big[k][0][0], split[k][0][0])
+        assert none[k][0] == (None, None, None)
+    one = lsq_reconstruct(g["helix_image"], s2, twists[5], rs, cs, interpolation="linear", **kw)
+    assert one[1] == big[5][1]
+    np.testing.assert_array_equal(one[0][0], big[5][0][0])
+    (full, h1, h2), score = lsq_reconstruct(g["helix_image"], s2, 29.0, rs, cs, interpolation="linear", fsc_test=2, **kw)
+    assert h1 is not None and h2 is not None and h1.shape == full.shape
+    s_full = lsq_reconstruct(g["helix_image"], s2, 29.0, rs, cs, interpolation="linear", **kw)[1]
+    assert abs(score - s_full) < 0.1 and not np.array_equal(h1, h2)
+
+
+def test_trilinear_with_tilt_takes_the_single_candidate_path(golden_dir):
+    """Out-of-plane tilt: a ray's samples cross cell layers, the group solver has no such products — the candidates go
+    through hh_pa from a thread pool, same results in list order."""
+    g = np.load(golden_dir / "g5_lsq.npz")
+    s2, rs, cs, kw = _helix_kw(g)
+    cands = [(27.0, rs, cs), (29.0, rs, cs)]
+    stats = {}
+    res = lsq_reconstruct_batch(g["helix_image"], s2, cands, tilt_degree=3.0, interpolation="linear", streams=2, stats=stats, **kw)
+    assert stats["path"] == "hh_pa"
     for (maps, score), (tw, r, c) in zip(res, cands):
-        (want_map, _, _), want = lsq_reconstruct(g["helix_image"], s2, tw, r, c, interpolation="linear", **kw)
+        (want_map, _, _), want = lsq_reconstruct(g["helix_image"], s2, tw, r, c, tilt_degree=3.0, interpolation="linear", **kw)
         assert score == want
         np.testing.assert_array_equal(maps[0], want_map)
-    none = lsq_reconstruct_batch(g["helix_image"], s2, cands[:1], interpolation="linear", return_3d=False, **kw)
-    assert none[0][0] == (None, None, None) and none[0][1] == res[0][1]
+
+
+def test_full_load_trilinear_and_concurrent_groups_are_reproducible():
+    """ADVICE (round 3): the load at which stale per-candidate state had shown (K = 256) and the shape that ships (several
+    groups on several streams) had no reproducibility test.  256 nearest-neighbour candidates in one group, twice; 512
+    candidates as 4 groups on 4 streams against one group on one stream (nn), and 128 trilinear candidates two ways: the
+    scores must agree bit for bit and the solver's self-check must stay at zero (it is an error now: hh_pab_solve returns
+    HH_ERR_STATE)."""
+    import helicon_amd as H
+
+    ny, nx, l3 = 64, 128, 16
+    eng = H.SweepEngine((ny, nx))
+    eng.set_geometry(apix=5.0, helical_diameter=0.5 * ny * 5.0, ball_radius=10.0)
+    img = eng.simulate(29.0, 20.0, 1).astype(np.float32)
+    kw = dict(reconstruct_diameter_2d_pixel=ny, reconstruct_diameter_3d_pixel=ny, reconstruct_length_2d_pixel=nx,
+              reconstruct_length_3d_pixel=l3, return_3d=False)
+
+    def scores(n, interp, batch, streams):
+        st = {}
+        res = lsq_reconstruct_batch(img, 1.0, [(float(t), 4.0, 1) for t in np.linspace(27.0, 31.0, n)], interpolation=interp,
+                                    batch=batch, streams=streams, stats=st, **kw)
+        assert st["self_check_failures"] == 0
+        return np.array([s for _, s in res]), np.array(st["info"])
+
+    a, ia = scores(256, "nn", 256, 1)
+    b, ib = scores(256, "nn", 256, 1)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ia, ib)
+    c, ic = scores(512, "nn", 128, 4)
+    d, id_ = scores(512, "nn", 512, 1)
+    np.testing.assert_array_equal(c, d)
+    np.testing.assert_array_equal(ic, id_)
+    e, _ = scores(128, "linear", 32, 4)
+    f, _ = scores(128, "linear", 128, 1)
+    np.testing.assert_array_equal(e, f)
+    assert abs(int(np.argmax(a)) - 128) <= 8 and abs(int(np.argmax(f)) - 64) <= 6       # the truth (29 degrees) is mid-list
