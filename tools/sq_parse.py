@@ -12,7 +12,8 @@ from collections import defaultdict
 KERNELS = ("k_fused_pass<512", "k_second_pass<512, 0, 1>", "k_first_pass_table<512>", "k_first_pass<512, 0>",
            "k_run_table<512>", "k_column_factors<512>", "k_fused_pass<1024", "k_second_pass<1024, 0, 1>",
            "k_first_pass_table<1024>", "k_first_pass<1024, 0>", "k_gen_rows<", "k_gen_fused<",
-           "k_segment_corr", "k_pabs_matvec<1", "k_pabs_rmatvec<1", "k_pabs_matvec<0", "k_pabs_matvec<2", "k_pabs_rmatvec<0")
+           "k_segment_corr", "k_pabs_matvec<1", "k_pabs_rmatvec<1", "k_pabs_matvec<0", "k_pabs_matvec<2", "k_pabs_rmatvec<0",
+           "k_pabf_matvec<1", "k_pabf_scatter<1", "k_pabl_finish<1", "k_pabf_tail<1", "k_pabl_matvec<1", "k_pabl_scatter<1")
 tot = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
 dur = defaultdict(list)
