@@ -50,9 +50,10 @@ def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
     parser.add_argument("--out", default=None, help=".npz with scores[S, C, T, R], twists, rises, csyms")
     parser.add_argument("--rescore", type=int, default=0, help="re-score this many best candidates per image with the least-squares scorer")
     parser.add_argument("--tube-diameter", type=float, default=None, help="Angstrom, for --rescore (default 0.8 * ny * apix)")
-    parser.add_argument("--interpolation", choices=("nn", "linear"), default="nn",
-                        help="for --rescore: nn = all candidates set up and solved together on the device; linear (the "
-                             "reference app's default) = one call per candidate from a thread pool")
+    parser.add_argument("--interpolation", choices=("nn", "linear"), default="linear",
+                        help="for --rescore: the projector of the least-squares scorer — linear (trilinear, the reference app's "
+                             "default, app.py:577-585) or nn (nearest neighbour); both set up and solve all candidates together "
+                             "on the device.  The two give different scores for the same candidate.")
     parser.add_argument("--threads", type=int, default=8, help="for --rescore")
     parser.add_argument("--map-out", default=None, help="for --rescore: write the best candidate's helically symmetrised map of every "
                         "image to <map-out>_<image>.mrc (the app's map download, app.py:1267-1287)")
@@ -100,23 +101,41 @@ def run(args) -> dict:
             report["images"][s]["rescored"] = rescore(images[s], report["images"][s]["top"][: args.rescore], args)
             if args.map_out and report["images"][s]["rescored"]:
                 report["images"][s]["map"] = write_best_map(images[s], report["images"][s]["rescored"][0], args, f"{args.map_out}_{s}.mrc")
+    if args.rescore > 0:
+        report["rescore_interpolation"] = args.interpolation
+        print(f"denovo3DBatch --rescore: least-squares scorer with interpolation = {args.interpolation}", file=sys.stderr)
     if args.out:
+        extra = {}
+        if args.rescore > 0:
+            extra = dict(rescore_interpolation=np.asarray(args.interpolation),
+                         rescored=np.asarray([[[r["twist"], r["rise"], r["csym"], r["sweep_score"],
+                                                np.nan if r["lsq_score"] is None else r["lsq_score"]]
+                                               for r in im.get("rescored", [])] for im in report["images"]], dtype=np.float64))
         np.savez_compressed(args.out, scores=res.scores, twists=twists, rises=rises, csyms=np.asarray(args.csym),
-                            params=res.grid.params, valid=res.grid.valid)
+                            params=res.grid.params, valid=res.grid.valid, **extra)
     return report
 
 
 def rescore(image, candidates, args) -> list:
     """The least-squares scorer on a list of sweep candidates (dicts with twist, rise, csym, score), best first.
 
-    With the nearest-neighbour projector the candidates go through ``lsq_reconstruct_batch``: they are grouped by
-    reconstruction box (the reference derives the box length from the candidate's rise, pipeline.py:259-266, 319-331) and
-    every group is set up and solved on the device at once — scores only, the display products of ``process_one_task``
-    (symmetrised map, projections) are made for the one map ``--map-out`` asks for.  With trilinear interpolation every
-    candidate is one ``process_one_task`` call from a thread pool, like the reference's driver (app.py:2473-2476)."""
+    With tilt = psi = 0 (the reference app's own setting, app.py:2344-2346) the candidates go through
+    ``lsq_reconstruct_batch`` with either projector: they are grouped by reconstruction box (the reference derives the box
+    length from the candidate's rise, pipeline.py:259-266, 319-331) and every group is set up and solved on the device at
+    once — scores only, the display products of ``process_one_task`` (symmetrised map, projections) are made for the one
+    map ``--map-out`` asks for.  With tilt / psi every candidate is one ``process_one_task`` call from a thread pool, like
+    the reference's driver (app.py:2473-2476).  Candidates with |twist| < 0.01 degree are skipped as the reference's
+    driver skips them (app.py:2389-2393).  Every record names the projector: the two give different scores."""
     ny, nx = image.shape
     tube_d = args.tube_diameter if args.tube_diameter is not None else 0.8 * ny * args.apix
-    if args.interpolation == "nn":
+    usable = [c for c in candidates if abs(c["twist"]) >= 0.01]   # the reference skips such pairs (app.py:2389-2393)
+    if len(usable) < len(candidates):
+        print(f"denovo3DBatch --rescore: {len(candidates) - len(usable)} candidate(s) with |twist| < 0.01 degree skipped "
+              "(the least-squares scorer divides by the twist)", file=sys.stderr)
+        candidates = usable
+    if not candidates:
+        return []
+    if args.tilt == 0 and args.psi == 0:   # the group solver (tilt / psi: process_one_task below, one call per candidate)
         from .denovo3D import _prepare_task_image, lsq_box
         from .solver import lsq_reconstruct_batch
 
@@ -133,11 +152,12 @@ def rescore(image, candidates, args) -> list:
                                                              for k in members],
                                         reconstruct_diameter_3d_inner_pixel=d3_inner, reconstruct_diameter_2d_pixel=d2,
                                         reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2, reconstruct_length_3d_pixel=l3,
-                                        sym_oversample=oversample, return_3d=False, device=args.device, streams=max(1, args.threads))
+                                        sym_oversample=oversample, return_3d=False, device=args.device, streams=max(1, args.threads),
+                                        interpolation=args.interpolation)
             for k, (_, sc) in zip(members, res):
                 scores[k] = sc
-        got = [dict(twist=c["twist"], rise=c["rise"], csym=c["csym"], sweep_score=c["score"], lsq_score=float(scores[k]))
-               for k, c in enumerate(candidates)]
+        got = [dict(twist=c["twist"], rise=c["rise"], csym=c["csym"], sweep_score=c["score"], lsq_score=float(scores[k]),
+                    interpolation=args.interpolation) for k, c in enumerate(candidates)]
         return sorted(got, key=lambda r: -r["lsq_score"])
 
     from concurrent.futures import ThreadPoolExecutor
@@ -150,7 +170,7 @@ def rescore(image, candidates, args) -> list:
                                0.0, 0, 0.0, 0, args.apix, "", 0, 0, 0, 0, args.apix, -1, -1, -1, tube_d, 0, -1, 1,
                                args.interpolation, 0, 0, "cosine", {"model": "lsq", "scorer": "lsq", "device": args.device}, 0, 1)
         return dict(twist=c["twist"], rise=c["rise"], csym=c["csym"], sweep_score=c["score"],
-                    lsq_score=None if out is None else float(out[0]))
+                    lsq_score=None if out is None else float(out[0]), interpolation=args.interpolation)
 
     with ThreadPoolExecutor(max_workers=max(1, args.threads)) as pool:
         got = list(pool.map(one, candidates))

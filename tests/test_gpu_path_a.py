@@ -258,6 +258,19 @@ def test_batch_driver_rescores_the_best_sweep_candidates(tmp_path):
                                 0, apix, "", 0, 0, 0, 0, apix, -1, -1, -1, 0.7 * ny * apix, 0, -1, 1, "nn", 0, 0, "cosine",
                                 {"model": "lsq", "scorer": "lsq"}, 0, 1)
     assert direct[0] == c["lsq_score"] and direct[1][3] is None      # bit-reproducible; return_3d = 0 keeps the map out
+    assert all(r["interpolation"] == "nn" for r in res) and rep["rescore_interpolation"] == "nn"
+    # the default projector is the reference app's (trilinear, app.py:577-585); the output names it; a zero twist is skipped
+    args2 = B.add_args(argparse.ArgumentParser()).parse_args(
+        [str(tmp_path / "img.npy"), "--apix", str(apix), "--twist", "28", "30", "1", "--rise", "19", "21", "1", "--top", "3",
+         "--helical-diameter", str(0.5 * ny * apix), "--rescore", "3", "--tube-diameter", str(0.7 * ny * apix), "--out", str(tmp_path / "o.npz")])
+    rep2 = B.run(args2)
+    assert args2.interpolation == "linear" and rep2["rescore_interpolation"] == "linear"
+    res2 = rep2["images"][0]["rescored"]
+    assert (res2[0]["twist"], res2[0]["rise"]) == (29.0, 20.0) and all(r["interpolation"] == "linear" for r in res2)
+    saved = np.load(tmp_path / "o.npz")
+    assert str(saved["rescore_interpolation"]) == "linear" and saved["rescored"].shape == (1, 3, 5)
+    zero = B.rescore(img, [dict(twist=0.0, rise=20.0, csym=1, score=0.1), dict(twist=29.0, rise=20.0, csym=1, score=0.9)], args2)
+    assert len(zero) == 1 and zero[0]["twist"] == 29.0
     from helicon_amd.mrc import read_mrc
 
     vol, vox = read_mrc(im["map"])                                   # the app's map download: (nx, ny, ny) voxels at the input's pixel size
