@@ -137,6 +137,8 @@ EXPORTS = {
     "hh_pab_check_ray_arithmetic": (C.c_int, [C.POINTER(hh_pa_params), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "hh_pab_matvec": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p]),
     "hh_pab_rmatvec": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p]),
+    "hh_pab_solve_prox": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _f64p, C.c_double, C.c_int, C.c_double, C.c_int,
+                                    _f32p, _f64p, C.POINTER(C.c_int32), _f64p]),
     "hh_pab_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 

@@ -757,7 +757,8 @@ def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, cs
     a3, d2, l2, d3, d3_inner, l3, sym_oversample = lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_length,
                                                           tube_diameter, tube_diameter_inner, reconstruct_length, sym_oversample,
                                                           return_3d)
-    model = {k: v for k, v in opts.items() if k in ("model",)} or {"model": "lsq"}
+    model = {k: v for k, v in opts.items() if k in ("model", "alpha", "l1_ratio")}   # app.py:2385-2387: model, l1_ratio (+ alpha)
+    model.setdefault("model", "lsq")
     (rec3d, set1, set2), score = lsq_reconstruct(
         img, a2 / a3, twist, rise / a3, csym, tilt, psi, dy / a2, thresh_fraction=thresh_fraction,
         positive_constraint=positive_constraint, reconstruct_diameter_3d_inner_pixel=d3_inner,

@@ -1,22 +1,22 @@
-"""Path A on the GPU, first slice: ``lsq_reconstruct`` with the reference's signature
+"""Path A on the GPU: ``lsq_reconstruct`` with the reference's signature
 (src/helicon/webApps/denovo3D/solver_linear_regression.py:31-56) for ``interpolation="nn"`` / ``"linear"`` and
-``algorithm=dict(model="lsq")`` — the deterministic configurations of the reference's scorer.
+``algorithm["model"]`` in lsq, elasticnet (the reference app's default), lasso, ridge, lreg.
 
 What runs where:
 
-* libhelicon_hip.so (``hh_pa_*``, csrc/path_a.inc): the implicit system — the voxel index of every projection-ray sample
-  under every symmetry operation (the reference's ``build_A_data_matrix``, its dominant cost, never materialised as a
-  matrix; with trilinear interpolation not even the indices are kept, every product recomputes the rays), the
-  symmetry-constraint rows (``build_A_helical_sym_matrix``), ``A x`` / ``A^T y`` and the whole LSMR iteration with its
-  vectors on the device;
-* this module: what ``scipy.optimize.lsq_linear(method="trf", lsq_solver="lsmr")`` does around those LSMR solves when
-  the solution is bounded (solver_linear_regression.py:245-269: ``lb = 0, ub = max(b)`` under the positivity rule of
-  :352-355) — the trust-region-reflective iteration of scipy/optimize/_lsq/trf_linear.py, O(n) vector arithmetic per
-  outer iteration — plus the cosine score (:484-530) and the volume assembly (:532-547).
+* libhelicon_hip.so, ``hh_pab_*`` (csrc/path_a_batch.inc, path_a_linear.inc, path_a_factored.inc): K candidates of one image
+  set up and solved together on the device — the implicit system (the reference's ``build_A_data_matrix`` /
+  ``build_A_helical_sym_matrix``, never materialised as matrices), LSMR and the whole trust-region-reflective loop of
+  ``scipy.optimize.lsq_linear`` (model "lsq"), or the accelerated proximal-gradient minimiser of the scikit-learn models'
+  common objective (``hh_pab_solve_prox``), the float32 map, the prediction and the cosine score.  ``lsq_reconstruct`` is
+  a batch of one (three with half sets);
+* ``hh_pa_*`` (csrc/path_a.inc): the single-candidate projector, kept for trilinear candidates with tilt / psi (rays that
+  cross cell layers) — products on the device, the trust-region glue of this module on the host — and as the parity
+  reference of the group solver's products;
+* this module: argument handling, the positivity rule (:352-355), grouping, half sets, the volume assembly (:532-547).
 
-Not in this slice (``NotImplementedError``): the scikit-learn models, the random half-set split
-(``fsc_test=1``), tilt/psi/dy refinement, scores other than cosine.  There is no CPU fallback: without the library or a
-GPU the call raises.
+Not provided (``NotImplementedError``): model "ard", tilt / psi / dy refinement, scores other than cosine.  There is no CPU
+fallback: without the library or a GPU the call raises.
 """
 from __future__ import annotations
 
@@ -220,6 +220,24 @@ class PathABatch:
             msg = self._L.hh_pab_last_error(self._h)
             raise _lib.HeliconHipError(f"libhelicon_hip (Path A batch) error {rc}: {msg.decode() if msg else '?'}")
         return x, scores, info
+
+    def solve_prox(self, positive, clip, alpha, l1_ratio, ridge_form=False, tol=1e-7, max_iter=5000, want_x=True):
+        """The scikit-learn models of solve_equations (solver:270-342) as the minimiser of their common objective
+        (``hh_pab_solve_prox``): (x float32 [K, n] or None, scores [K], info [K, 3] = iterations / converged / non-zeros,
+        objective [K])."""
+        pos = np.ascontiguousarray(np.broadcast_to(np.asarray(positive, dtype=np.int32), (self.count,)))
+        clp = np.ascontiguousarray(np.broadcast_to(np.asarray(clip, dtype=np.int32), (self.count,)))
+        al = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float64), (self.count,)))
+        x = np.empty((self.count, self.n), dtype=np.float32) if want_x else None
+        scores = np.empty(self.count, dtype=np.float64)
+        info = np.empty((self.count, 3), dtype=np.int32)
+        obj = np.empty(self.count, dtype=np.float64)
+        i32 = C.POINTER(C.c_int32)
+        self._check(self._L.hh_pab_solve_prox(self._h, pos.ctypes.data_as(i32), clp.ctypes.data_as(i32), _p(al), float(l1_ratio),
+                                              1 if ridge_form else 0, float(tol), int(max_iter),
+                                              None if x is None else x.ctypes.data_as(C.POINTER(C.c_float)), _p(scores),
+                                              info.ctypes.data_as(i32), _p(obj)))
+        return x, scores, info, obj
 
     def matvec(self, c, x):
         """A_c x through the solve's own product kernels (rows in the reference's order)."""
@@ -457,11 +475,30 @@ def _box(img, reconstruct_diameter_2d_pixel, reconstruct_length_2d_pixel, recons
     return d2, l2, d3, l3, mask, n3, target
 
 
+def _model_of(algorithm):
+    """algorithm dict of lsq_reconstruct -> None for "lsq", else (alpha, l1_ratio, ridge_form) of the common objective
+    (solver:270-342: the defaults of the reference's constructors)."""
+    algorithm = algorithm or {}
+    model = algorithm.get("model", "lsq")
+    if model == "lsq":
+        return None
+    if model == "elasticnet":
+        return float(algorithm.get("alpha", 1e-4)), float(algorithm.get("l1_ratio", 0.5)), False
+    if model == "lasso":
+        return float(algorithm.get("alpha", 1e-4)), 1.0, False
+    if model == "ridge":
+        return float(algorithm.get("alpha", 1)), 0.0, True
+    if model == "lreg":
+        return 0.0, 0.0, False
+    raise NotImplementedError(f"algorithm model {model!r}: the GPU path has lsq, elasticnet, lasso, ridge and lreg (ard is a dense "
+                              "Bayesian fit in the reference)")
+
+
 def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degree=0, psi_degree=0, dy_pixel=0,
                           thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                           reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
                           reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, interpolation="nn", return_3d=True,
-                          device=0, batch=128, streams=8, stats=None):
+                          device=0, batch=128, streams=8, stats=None, algorithm=None):
     """``lsq_reconstruct`` (solver_linear_regression.py:31-547; nearest-neighbour projector, model "lsq", cosine score)
     for MANY (twist_degree, rise_pixel, csym) candidates of one image: the loop the reference's driver runs as a thread
     pool over ``process_one_task`` (app.py:2473-2476).  ``candidates`` is a sequence of ``(twist, rise, csym)``; the
@@ -481,6 +518,9 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     cands = [(float(t), float(r), int(c)) for t, r, c in candidates]
     if interpolation not in ("nn", "linear"):
         raise ValueError("interpolation must be 'nn' or 'linear'")
+    model = _model_of(algorithm)
+    if model is not None and (tilt_degree != 0 or psi_degree != 0):
+        raise NotImplementedError("the scikit-learn models run on the slice-major products: tilt = psi = 0")
 
     def one_by_one():
         """The single-candidate path (hh_pa) from a thread pool: trilinear candidates the group solver cannot slice."""
@@ -499,7 +539,7 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
             stats.update(groups=len(cands), launches=0, host_syncs=0, lsmr_iterations_queued=0, self_check_failures=0, info=[], path="hh_pa")
         return res
 
-    if interpolation == "linear" and (tilt_degree != 0 or psi_degree != 0):
+    if interpolation == "linear" and (tilt_degree != 0 or psi_degree != 0) and model is None:
         if fsc_test == 1:
             raise NotImplementedError("fsc_test=1 with trilinear interpolation needs tilt = psi = 0 (the group solver)")
         return one_by_one()
@@ -532,7 +572,26 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
             if B.n != n3:
                 raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
                                  "the 3-D diameter): the reference's two masks would rank the voxels differently")
-            x, scores, info = B.solve(positive, 1 if thresh_fraction >= 0 else 0, want_x=return_3d)
+            clip = 1 if thresh_fraction >= 0 else 0
+            if model is None:
+                x, scores, info = B.solve(positive, clip, want_x=return_3d)
+            else:
+                alpha, rho, ridge_form = model
+                al = np.full(len(params), alpha, dtype=np.float64)
+                x, scores, info3, _ = B.solve_prox(positive, clip, al, rho, ridge_form, want_x=return_3d)
+                # solver:331-338: an all-zero solution is refitted with alpha / 10 (elasticnet, lasso, ridge) until it is not
+                for _ in range(12):
+                    zero = info3[:, 2] == 0
+                    if not zero.any() or alpha == 0:
+                        break
+                    al = np.where(zero, al * 0.1, al)
+                    x2, s2, i2, _ = B.solve_prox(positive, clip, al, rho, ridge_form, want_x=return_3d)
+                    scores = np.where(zero, s2, scores)
+                    info3 = np.where(zero[:, None], i2, info3)
+                    if return_3d:
+                        x = np.where(zero[:, None], x2, x)
+                info = np.concatenate([np.where(info3[:, 1:2] == 1, 1, 0), info3[:, :1], np.zeros_like(info3[:, :1]), info3[:, :1],
+                                       np.zeros_like(info3[:, :1])], axis=1)   # status, iterations, -, iterations, -
             pids = [B.rhs(c)[1] for c in range(len(params))] if random_split else None
             counters = dict(B.counters(), device_bytes=B.device_bytes, info=info.tolist())
         return x, scores, counters, pids
@@ -623,18 +682,20 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     tests against its fixture; against the float64 oracle the agreement is that of "nn"."""
     if interpolation not in ("nn", "linear"):
         raise ValueError("interpolation must be 'nn' or 'linear'")
-    if (algorithm or {}).get("model", "lsq") != "lsq":
-        raise NotImplementedError("the GPU slice of Path A provides model='lsq' (the scikit-learn models are not deterministic)")
+    model = _model_of(algorithm)
     if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
         raise NotImplementedError("scores other than cosine need scikit-image")
     if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):
         raise NotImplementedError("tilt / psi / dy refinement is outside this slice")
     img = np.asarray(projection_image)
+    if _single and model is not None:
+        raise NotImplementedError("the scikit-learn models run in the group solver")
     if interpolation == "nn" or not _single:   # the device-resident solver (a batch of one, or of three with half sets)
         return lsq_reconstruct_batch(img, scale2d_to_3d, [(twist_degree, rise_pixel, csym)], tilt_degree, psi_degree, dy_pixel,
                                      thresh_fraction, positive_constraint, reconstruct_diameter_3d_inner_pixel,
                                      reconstruct_diameter_2d_pixel, reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel,
-                                     reconstruct_length_3d_pixel, sym_oversample, fsc_test, interpolation=interpolation, device=device)[0]
+                                     reconstruct_length_3d_pixel, sym_oversample, fsc_test, interpolation=interpolation, device=device,
+                                     algorithm=algorithm)[0]
     d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
     d2 = int(reconstruct_diameter_2d_pixel) if reconstruct_diameter_2d_pixel > 0 else img.shape[0]
     l2 = int(reconstruct_length_2d_pixel) if reconstruct_length_2d_pixel > 0 else img.shape[1]

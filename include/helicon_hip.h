@@ -359,6 +359,16 @@ int hh_pab_check_ray_arithmetic(const hh_pa_params* params, int ny, int nx, int 
  * x, g: [unknowns], y: [data rows + symmetry rows], host float64.  For the parity tests; not during a solve. */
 int hh_pab_matvec(hh_pab* pab, int c, const double* x, double* y);
 int hh_pab_rmatvec(hh_pab* pab, int c, const double* y, double* g);
+/* The scikit-learn models of solve_equations (solver_linear_regression.py:270-342: ElasticNet — the reference app's default,
+ * app.py:555-558 —, Lasso, Ridge, LinearRegression, all with fit_intercept = True) for every candidate: the minimiser of
+ *   (1 / 2m) || (b - mean b) - (A - 1 mu^T) w ||^2 + alpha[c] l1_ratio |w|_1 + alpha[c] (1 - l1_ratio) / 2 |w|^2,  w >= 0 where positive[c]
+ * (mu = column means of A, m = rows; ridge_form: alpha[c] / m, the scaling of sklearn's Ridge) by accelerated proximal gradient
+ * on the implicit operator, float64; x -> float32 and the cosine score as hh_pab_solve.  The reference's solvers visit the
+ * coordinates in a random order and stop loosely, in float32: for l1_ratio < 1 (or full column rank) the minimiser is unique and
+ * this is it.  tol: max |w_new - w| <= tol max |w_new|.  info: [count][3] = {iterations, converged, non-zero coefficients};
+ * objective: [count] value of the function above at w; x_out, info, objective may be NULL.  Needs tilt = psi = 0. */
+int hh_pab_solve_prox(hh_pab* pab, const int32_t* positive, const int32_t* clip, const double* alpha, double l1_ratio, int ridge_form,
+                      double tol, int max_iter, float* x_out, double* scores, int32_t* info, double* objective);
 /* counters of the last hh_pab_solve: {kernel launches, host synchronisations, LSMR iterations queued, failures of the
  * solver's self-check (every workgroup of a launch saw the per-candidate state the previous launch wrote; must be 0)} */
 int hh_pab_counters(const hh_pab* pab, int64_t out[4]);

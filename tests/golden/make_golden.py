@@ -540,10 +540,43 @@ def g13_fsc_random():
     np.savez_compressed(OUT / "g13_fsc_random.npz", **out)
 
 
+def g14_sklearn_models():
+    """lsq_reconstruct with the scikit-learn models of solve_equations (solver:270-342): elasticnet (the app's default,
+    app.py:555-558), lasso, ridge, lreg — on the helix of fixture G5 at three twists, both projectors, positivity rule on.
+    ElasticNet / Lasso use selection="random" with the global NumPy RNG: five seeds each, all scores stored (their spread is
+    the reference's own run-to-run band) and the seed-0 map (the solution, for its objective value).  lreg (dense NNLS, 200 s
+    per call without numba) only at the true twist."""
+    from helicon.webApps.denovo3D.solver_linear_regression import lsq_reconstruct
+    import sklearn
+
+    g5 = np.load(OUT / "g5_lsq.npz")
+    img = g5["helix_image"]
+    kw = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, reconstruct_length_2d_pixel=32,
+              reconstruct_length_3d_pixel=6, sym_oversample=1)
+    out = {"image": img, "twists": np.asarray([25.0, 29.0, 33.0]), "seeds": np.arange(5), "sklearn_version": np.asarray(sklearn.__version__)}
+    for model in ("elasticnet", "lasso", "ridge", "lreg"):
+        for interp in ("nn", "linear"):
+            twists = (29.0,) if model == "lreg" else (25.0, 29.0, 33.0)
+            seeds = range(5) if model in ("elasticnet", "lasso") else range(1)
+            scores = np.zeros((len(twists), len(list(seeds))))
+            for ti, tw in enumerate(twists):
+                for si, seed in enumerate(seeds):
+                    np.random.seed(seed)
+                    (rec, _, _), score = lsq_reconstruct(img.copy(), 1.0, tw, 2.0, 1, interpolation=interp,
+                                                         algorithm=dict(model=model, l1_ratio=0.5), **kw)
+                    scores[ti, si] = score
+                    if si == 0:
+                        out[f"{model}_{interp}_rec_{int(tw)}"] = rec
+            out[f"{model}_{interp}_scores"] = scores
+            print("g14", model, interp, scores.round(6).tolist())
+    np.savez_compressed(OUT / "g14_sklearn_models.npz", **out)
+
+
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random]
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random,
+              g14_sklearn_models]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:
         if not only or make.__name__ in only:
