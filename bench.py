@@ -483,8 +483,12 @@ def config_legs(args, torch, dev):
                                "kernel": "k_fused_pass" if shape == ny == nx and (ny & (ny - 1)) == 0 else "k_gen_rows (nx = R1 R2; gen_rows.hip)",
                                "note": "device time of the whole step (sweep + arg-max + D2H), events on the sweep's stream"}
         else:
-            # several segments: the masked spectrum q of every candidate is stored once and read once (K bins x 4 B each way)
+            # several segments: the masked spectrum q of every candidate is stored once and read once (K bins x 4 B each way);
+            # tuned sizes up to 512 keep only the bins with weight (round 4), in slices of 512
             k_bins = (ny // 2 + 1) * nx
+            if shape == ny == nx and (ny & (ny - 1)) == 0 and ny <= 512:
+                m = H.radial_band_mask(ny, nx)
+                k_bins = -(-int(m[ny // 2:, :].sum() + m[0, :].sum()) // 512) * 512
             moved = 2.0 * 4 * k_bins
             gbps = moved * cps / 1e9
             leg["scores_per_s"] = cps * segments

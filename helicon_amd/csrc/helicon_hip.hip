@@ -106,6 +106,9 @@
 #ifndef HH_KF_STAGGER
 #define HH_KF_STAGGER 1    // fused pass (N = 512): wavefronts 4-7 run half a candidate behind wavefronts 0-3
 #endif
+#ifndef HH_KF_DEFER_Q
+#define HH_KF_DEFER_Q 1    // fused pass, several segments: the early wavefronts store a candidate's q at the top of the next round
+#endif
 #ifndef HH_KF_CUT
 #define HH_KF_CUT 1        // fused pass: part A of a candidate ends after the butterflies of this transform stage
 #endif
@@ -1145,7 +1148,11 @@ struct SecondArgs {
   const float2* w2;       // [N/2+1][T][8] {w, w*(E-Ebar)} at kx = t + 64 m: a lane's 8 bins are contiguous (EPI_SCORE)
   double* partials;       // [B][NPART][3]: moments per spectrum row (and wavefront of the row)  (EPI_SCORE)
   float2* spec_out;       // [B][N/2+1][N]                     (EPI_STORE)
-  float* q_out;           // [B][N/2+1][N] masked q, rows lane-major (bin kx = wl + m N/8 at [wl][m]) (EPI_QSTORE)
+  float* q_out;           // EPI_QSTORE: the masked q of every candidate.  Compact (q_roff != NULL, N <= 512): only the bins with
+                          // weight, [B][q_stride], row r's bins from q_roff[r] on in ascending kx; else [B][N/2+1][N], rows
+                          // lane-major (bin kx = wl + m N/8 at [wl][m])
+  const int* q_roff;      // [N/2+1] first compact position of a spectrum row's bins (NULL: the full layout)
+  size_t q_stride;        // floats per candidate in q_out
   const int* kb_list;     // ky blocks to process (ascending); NULL = all N/16 of them
   int n_kb;               // entries of kb_list (or N/16)
   int batch;              // candidates in this launch
@@ -1153,6 +1160,46 @@ struct SecondArgs {
 };
 
 constexpr int EPI_SCORE = 0, EPI_STORE = 1, EPI_QSTORE = 2;  // 2: several segments — keep q for the contraction
+
+// Several segments, compact q (round 4): a spectrum row stores only its bins with weight, in ascending kx.  Lane t of the
+// row's transform holds the bins kx = t + m T: for a fixed m the row's T lanes are T consecutive bins, so a bin's position
+// is the row's offset + the weights counted over the earlier m + the lanes below t with weight in this m — a ballot and
+// two population counts per m, once per workgroup (the weights do not change with the candidate).  pos[m] = -1: no weight.
+// The same as masks and running bases — for T = 64 both are wave-uniform (scalar registers: the fused pass has no vector
+// register to spare) — and the position of lane t's bin m from them: two mbcnt instructions.
+template <int T>
+struct CompactRow {
+  unsigned long long mask[8];
+  int base[8];
+};
+template <int T>
+__device__ __forceinline__ CompactRow<T> compact_row(const float (&wx)[8], int base, int lane_in_wave) {
+  static_assert(T <= 64, "a row's lanes sit in one wavefront");
+  CompactRow<T> r;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const unsigned long long bal = __ballot(wx[m] > 0.f);
+    r.mask[m] = T >= 64 ? bal : (bal >> (lane_in_wave / T * T)) & ((1ull << (T & 63)) - 1ull);
+    r.base[m] = base;
+    base += __popcll(r.mask[m]);
+  }
+  return r;
+}
+template <int T>
+__device__ __forceinline__ int compact_pos(const CompactRow<T>& r, int m, int t) {   // -1: the bin has no weight
+  return ((r.mask[m] >> t) & 1ull) ? r.base[m] + __popcll(r.mask[m] & ((1ull << t) - 1ull)) : -1;
+}
+template <int T>
+__device__ __forceinline__ void compact_positions(const float (&wx)[8], int base, int t, int lane_in_wave, int pos[8]) {
+  static_assert(T <= 64, "a row's lanes sit in one wavefront");
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const unsigned long long bal = __ballot(wx[m] > 0.f);
+    const unsigned long long mine = T >= 64 ? bal : (bal >> (lane_in_wave / T * T)) & ((1ull << (T & 63)) - 1ull);
+    pos[m] = wx[m] > 0.f ? base + __popcll(mine & ((1ull << t) - 1ull)) : -1;
+    base += __popcll(mine);
+  }
+}
 
 template <int N>
 struct KB {
@@ -1299,6 +1346,19 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 256 ? KB<N>::WAVES_PER_SIMD :
       }
     }
   }
+  // several segments, compact q: where this lane's bins go inside a candidate's q (row `row`, and row N/2 for the packed row's group)
+  int qpos[8], qposn[8];
+  bool compact = false;
+  if constexpr (EPI == EPI_QSTORE && T <= 64) {
+    compact = a.q_roff != nullptr;
+    if (compact) {
+      float wx[8], wnx[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { wx[m] = w[m].x; wnx[m] = wn[m].x; }
+      compact_positions<T>(wx, a.q_roff[row], t, tid & 63, qpos);
+      compact_positions<T>(wnx, a.q_roff[N / 2], t, tid & 63, qposn);
+    }
+  }
 
   // A ky block is N/2 lines = 4N 16-byte pieces, contiguous in memory: piece q = pair*8 + r holds
   // H[ky = 8 kb + r][x = 2 pair, 2 pair + 1].  Every thread moves 4 pieces (coalesced 16 B/lane).
@@ -1363,9 +1423,15 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 256 ? KB<N>::WAVES_PER_SIMD :
             if constexpr (EPI == EPI_QSTORE) {
               // (q rows are stored lane-major, bin kx = t + m T at [t][m] like W2: a lane's eight bins are 32 contiguous
               // bytes; k_segment_corr only needs q and the segments' spectra in the SAME order)
-              float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
-              q0row[t * 8 + m] = w[m].x > 0.f ? q0 : 0.f;
-              q0row[(size_t)(N / 2) * N + t * 8 + m] = wn[m].x > 0.f ? qn : 0.f;
+              if (compact) {
+                float* const qb = a.q_out + b * a.q_stride;
+                if (qpos[m] >= 0) qb[qpos[m]] = q0;
+                if (qposn[m] >= 0) qb[qposn[m]] = qn;
+              } else {
+                float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;
+                q0row[t * 8 + m] = w[m].x > 0.f ? q0 : 0.f;
+                q0row[(size_t)(N / 2) * N + t * 8 + m] = wn[m].x > 0.f ? qn : 0.f;
+              }
             } else {
               a3 += w[m].y * q0;
               n3 += wn[m].y * qn;
@@ -1403,10 +1469,15 @@ __global__ __launch_bounds__(KB<N>::THREADS, (N >= 256 ? KB<N>::WAVES_PER_SIMD :
         const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
         s1 += w[m].x * q;
         s2 += w[m].x * q * q;
-        if constexpr (EPI == EPI_QSTORE)
-          qrow[t * 8 + m] = w[m].x > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
-        else
+        if constexpr (EPI == EPI_QSTORE) {
+          if (compact) {
+            if (qpos[m] >= 0) a.q_out[b * a.q_stride + qpos[m]] = q;
+          } else {
+            qrow[t * 8 + m] = w[m].x > 0.f ? q : 0.f;  // bins outside the mask carry no weight in any segment
+          }
+        } else {
           s3 += w[m].y * q;
+        }
       }
       group_sum3<TL>(s1, s2, s3);
       if (writer) {
@@ -1538,7 +1609,9 @@ struct FusedArgs {
   const int* cgs;         // [B][N/4 + 4]
   const float2* w2;
   double* partials;
-  float* q_out;           // EPI_QSTORE
+  float* q_out;           // EPI_QSTORE (layout: SecondArgs)
+  const int* q_roff;
+  size_t q_stride;
   const int* kb_list;
   int n_kb;
   int batch;              // candidates in this launch
@@ -1686,6 +1759,30 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     }
   }
 
+  // several segments, compact q: where this lane's bins go inside a candidate's q
+  // (positions are worked out at the store — one compare, two mbcnt, one scalar count per bin: this kernel has neither a
+  // vector nor a scalar register left to keep eight masks and bases across the candidates)
+  bool compact = false;
+  int qrow_base = 0;
+  if constexpr (EPI == EPI_QSTORE && T <= 64) {
+    compact = a.q_roff != nullptr;
+    if (compact) qrow_base = a.q_roff[row];
+  }
+  // candidate b's eight q of this lane -> its compact row
+  auto store_q_compact = [&](size_t b, const float (&qv)[8]) {
+    if constexpr (T <= 64) {
+      float* const qb = a.q_out + b * a.q_stride;
+      int base = qrow_base;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const unsigned long long bal = __ballot(w[m].x > 0.f);
+        const unsigned long long mine = T >= 64 ? bal : (bal >> ((tid & 63) / T * T)) & ((1ull << (T & 63)) - 1ull);
+        if (w[m].x > 0.f) qb[base + __popcll(mine & ((1ull << (t & 63)) - 1ull))] = qv[m];
+        base += __popcll(mine);
+      }
+    }
+  };
+
   // the run's table slice of this ky block, transposed to [ky in block][table row]; rows past the
   // run's own count are zero
   {
@@ -1729,6 +1826,9 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   constexpr int KCUT = (HH_KF_CUT < Plan<NF>::n) ? HH_KF_CUT : 1;  // A ends at the exchange after this stage
   const bool late = STAGGER && __builtin_amdgcn_readfirstlane(tid >> 6) >= (N / 64) / 2;
   if (HH_KF_PRIO && late) __builtin_amdgcn_s_setprio(HH_KF_PRIO);
+
+  // (see flush_q) — not for the packed row's group (its two rows are un-packed through the exchange buffer)
+  const bool defer_q = EPI == EPI_QSTORE && STAGGER && HH_KF_DEFER_Q && !late && !(kb == 0 && gi == 0);
 
   auto part_a = [&](int cc) {
     const int cur = cc & 1;
@@ -1852,6 +1952,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
         // the packed row also carries ky = N/2: its weights come from L2 here (one wavefront in 256)
         const float2* const nrow = a.w2 + ((size_t)(N / 2) * T + wl) * 8;
         float a1 = 0.f, a2 = 0.f, a3 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+        [[maybe_unused]] int nbase = (EPI == EPI_QSTORE && compact) ? a.q_roff[N / 2] : 0, zbase = qrow_base;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const float2 wnm = nrow[m];
@@ -1867,9 +1968,22 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
           n1 += wnm.x * qn;
           n2 += wnm.x * qn * qn;
           if constexpr (EPI == EPI_QSTORE) {
-            float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;   // (lane-major rows: kx = wl + m T at [wl][m])
-            q0row[wl * 8 + m] = w[m].x > 0.f ? q0 : 0.f;
-            q0row[(size_t)(N / 2) * N + wl * 8 + m] = wnm.x > 0.f ? qn : 0.f;
+            if constexpr (T <= 64) {
+              if (compact) {   // row N/2's weights arrive per candidate: its positions with them (one wavefront in 256)
+                const unsigned long long bal = __ballot(wnm.x > 0.f);
+                float* const qb = a.q_out + b * a.q_stride;
+                const unsigned long long bal0 = __ballot(w[m].x > 0.f);
+                if (w[m].x > 0.f) qb[zbase + __popcll(bal0 & ((1ull << t) - 1ull))] = q0;
+                zbase += __popcll(bal0);
+                if (wnm.x > 0.f) qb[nbase + __popcll(bal & ((1ull << t) - 1ull))] = qn;
+                nbase += __popcll(bal);
+              }
+            }
+            if (!compact) {
+              float* const q0row = a.q_out + b * (size_t)(N / 2 + 1) * N;   // (lane-major rows: kx = wl + m T at [wl][m])
+              q0row[wl * 8 + m] = w[m].x > 0.f ? q0 : 0.f;
+              q0row[(size_t)(N / 2) * N + wl * 8 + m] = wnm.x > 0.f ? qn : 0.f;
+            }
           } else {
             a3 += w[m].y * q0;
             n3 += wnm.y * qn;
@@ -1893,15 +2007,30 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     if (!scored) {
       float s1 = 0.f, s2 = 0.f, s3 = 0.f;
       float* const qrow = (EPI == EPI_QSTORE) ? a.q_out + (b * (size_t)(N / 2 + 1) + row) * N : nullptr;
+      [[maybe_unused]] float qkeep[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const float q = (HH_ABLATE & 32) ? v[m].x + v[m].y : amp_to_q<LOG>(v[m]);
         s1 += w[m].x * q;
         s2 += w[m].x * q * q;
-        if constexpr (EPI == EPI_QSTORE)
-          qrow[wl * 8 + m] = w[m].x > 0.f ? q : 0.f;   // lane-major: two 16-byte stores per lane and row
-        else
+        if constexpr (EPI == EPI_QSTORE) {
+          if (defer_q || compact) {
+            qkeep[m] = q;   // compact: stored below / deferred: at the top of the next round (flush_q)
+          } else {
+            qrow[wl * 8 + m] = w[m].x > 0.f ? q : 0.f;   // lane-major: two 16-byte stores per lane and row
+          }
+        } else {
           s3 += w[m].y * q;
+        }
+      }
+      if constexpr (EPI == EPI_QSTORE) {
+        if (defer_q) {   // the row's q into the group's own exchange buffer (free until the next candidate's panel)
+          float4* const st = reinterpret_cast<float4*>(fbuf) + 2 * tf;
+          st[0] = make_float4(qkeep[0], qkeep[1], qkeep[2], qkeep[3]);
+          st[1] = make_float4(qkeep[4], qkeep[5], qkeep[6], qkeep[7]);
+        } else if (compact) {
+          store_q_compact(b, qkeep);   // only the bins with weight: a fifth fewer bytes under the radial band
+        }
       }
       group_sum3<TL>(s1, s2, s3);
       if (writer) {
@@ -1912,9 +2041,30 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
       }
     }
   };
+  // Several segments: the q stores of a candidate must not sit right in front of the round's s_waitcnt vmcnt(0) (it retires
+  // the LDS-DMA copies, and on this chip stores count on vmcnt too): the wavefronts that run A then B issued them last and then
+  // waited out their whole latency, every round — the fused pass with q stores took 7.0 ms per 20,000 candidates against 3.9
+  // without.  Those wavefronts park the row's q in their exchange buffer and store it at the top of the NEXT round, so the
+  // stores have a round to land; the late wavefronts (B of the previous candidate first) had that order already.
+  auto flush_q = [&](int cc) {
+    if constexpr (EPI == EPI_QSTORE) {
+      const size_t b = (size_t)(cfirst + cc);
+      const float4* const st = reinterpret_cast<const float4*>(fbuf) + 2 * tf;
+      const float4 q0 = st[0], q1 = st[1];
+      const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      if (compact) {
+        store_q_compact(b, qv);
+      } else {
+        float* const qrow = a.q_out + (b * (size_t)(N / 2 + 1) + row) * N;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) qrow[wl * 8 + m] = w[m].x > 0.f ? qv[m] : 0.f;
+      }
+    }
+  };
 
 #pragma unroll 1
   for (int it = 0; it < nc; ++it) {
+    if (defer_q && it > 0) flush_q(it - 1);
     // next candidate's column factors: copied global -> LDS by the load unit itself (no registers, no ds_write
     // pass) into the other factor buffer, which nobody reads before the barrier at the end of this round
     // (an explicit s_waitcnt vmcnt(0) ahead of that barrier retires the copies).  One wave-instruction moves
@@ -1942,6 +2092,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     if (!(HH_ABLATE & 16384)) __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
   }
   if (late) part_b(nc - 1);
+  if (defer_q) flush_q(nc - 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2423,6 +2574,10 @@ struct hh_ctx {
   size_t cap_argmax = 0;
   size_t cap_w2 = 0, cap_wec = 0, cap_q = 0, cap_cpart = 0, cap_ref = 0, cap_psum = 0, cap_kb = 0;  // bytes
   int* d_kb_list = nullptr;      // ky blocks (8 rows) the mask touches, ascending; block 0 always
+  int* d_q_roff = nullptr;       // S > 1, N <= 512: compact q — first position of every spectrum row's weighted bins
+  size_t cap_q_roff = 0;
+  size_t q_stride = 0;           // S > 1: floats per candidate in d_q (compact: weighted bins, rounded up to 512; else (N/2+1) N)
+  int q_slices = 0;              // compact: 512-bin slices of the flat axis the contraction walks
   int* d_seg_rows = nullptr;     // S > 1: spectrum rows with any weight, ascending (the contraction skips the others)
   size_t cap_seg_rows = 0;
   int n_seg_rows = 0;
@@ -2825,11 +2980,12 @@ int scores_tail(hh_ctx* c, int64_t g, int64_t g0, int nb, bool last, float* d_sc
   } else {
     // several segments: one MFMA contraction of the batch's q against all segments' centred
     // spectra, then Pearson per (segment, candidate)
-    const int rows = c->n_seg_rows;   // rows the mask gives any weight
-    const size_t K = (size_t)(c->n / 2 + 1) * c->n;
+    // compact q: the flat axis of weighted bins in slices of 512; else one spectrum row per slice, those the mask gives any weight
+    const int rows = c->q_slices ? c->q_slices : c->n_seg_rows;
+    const size_t K = c->q_slices ? c->q_stride : (size_t)(c->n / 2 + 1) * c->n;
     ProfScope ps(c, 2);
     hipLaunchKernelGGL(k_segment_corr, dim3(rows, (nb + 255) / 256, c->s_pad / 64), dim3(256), 0, c->stream, c->d_q,
-                       c->d_wec, c->n, K, c->b_pad, c->s_pad, c->d_cpart, c->d_seg_rows);
+                       c->d_wec, c->q_slices ? 512 : c->n, K, c->b_pad, c->s_pad, c->d_cpart, c->q_slices ? (const int*)nullptr : c->d_seg_rows);
     const int total = nb * c->n_segments;
     hipLaunchKernelGGL(k_sum_partials, dim3(std::min(1024, (nb + 3) / 4)), dim3(256), 0, c->stream, partials, npart,
                        nb, c->d_psum);
@@ -2855,6 +3011,8 @@ int second_and_scores(hh_ctx* c, int64_t g, int64_t g0, int nb, bool last, float
     rc = dispatch_second<EPI_SCORE>(c, sa, nb);
   } else {
     sa.q_out = c->d_q;  // several segments: q of the batch -> HBM for the contraction
+    sa.q_roff = c->q_slices ? c->d_q_roff : nullptr;
+    sa.q_stride = c->q_stride;
     rc = dispatch_second<EPI_QSTORE>(c, sa, nb);
   }
   if (rc) return rc;
@@ -2990,12 +3148,12 @@ int ensure_partials(hh_ctx* c, int batch) {
 int ensure_segment_buffers(hh_ctx* c, int batch) {
   const int want = (std::max(batch, 64) + 63) / 64 * 64;
   if (want <= c->b_pad && c->d_q && c->d_cpart && c->d_psum) return HH_OK;
-  const size_t nh = (size_t)(c->n / 2 + 1) * c->n;
+  const size_t nh = c->q_stride ? c->q_stride : (size_t)(c->n / 2 + 1) * c->n;
   int rc;
   if ((rc = ensure_bytes(c, (void**)&c->d_q, &c->cap_q, (size_t)want * nh * sizeof(float)))) return rc;
   if ((rc = ensure_bytes(c, (void**)&c->d_cpart, &c->cap_cpart, (size_t)(c->n / 2 + 1) * want * c->s_pad * sizeof(float)))) return rc;
   if ((rc = ensure_bytes(c, (void**)&c->d_psum, &c->cap_psum, (size_t)want * 3 * sizeof(double)))) return rc;
-  HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)want * nh * sizeof(float), c->stream));  // pad rows of a batch stay finite
+  HH_HIP(c, hipMemsetAsync(c->d_q, 0, (size_t)want * nh * sizeof(float), c->stream));  // pad rows of a batch (and, compact, the pad bins of a row of q) stay finite
   c->b_pad = want;
   return HH_OK;
 }
@@ -3153,6 +3311,8 @@ int sweep_runs(hh_ctx* c, const double* d_params, int64_t g, float* d_scores, co
       double* const part = c->d_partials + (size_t)half * bmax * npart_for(c->n) * 3;
       fu.partials = part;
       fu.q_out = c->n_segments > 1 ? c->d_q : nullptr;
+      fu.q_roff = c->n_segments > 1 && c->q_slices ? c->d_q_roff : nullptr;
+      fu.q_stride = c->q_stride;
       fu.kb_list = c->d_kb_list;
       fu.n_kb = c->n_kb;
       fu.batch = bt.nb;
@@ -3483,6 +3643,7 @@ void hh_destroy(hh_ctx* c) try {
   (void)hipFree(c->d_ref);
   (void)hipFree(c->d_kb_list);
   (void)hipFree(c->d_seg_rows);
+  (void)hipFree(c->d_q_roff);
   (void)hipFree(c->d_table);
   (void)hipFree(c->d_eg);
   (void)hipFree(c->d_cgs);
@@ -3683,7 +3844,24 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
   // several segments: the shared-twist pipelines batch up to HH_SEG_BATCH candidates (q of a batch lives in HBM:
   // 0.5 MB per candidate at N = 512), the general pipeline max_batch
   std::vector<float2> w2(nh);
-  std::vector<float> wecm(multi ? (size_t)s_pad * nh : 0, 0.f);
+  // several segments, N <= 512: q and the centred spectra keep only the bins with weight (a fifth fewer bytes through HBM
+  // under the radial band, most of them under a resolution-limited or layer-line mask): row r's bins from roff[r] on, in
+  // ascending kx — the order the kernels' ballots give (compact_positions)
+  const bool compact = multi && n <= 512 && std::getenv("HH_Q_FULL") == nullptr;
+  std::vector<int> roff((size_t)n / 2 + 2, 0), cpos(compact ? nh : 0, -1);
+  size_t q_stride = nh;
+  if (compact) {
+    int at = 0;
+    for (int r = 0; r <= n / 2; ++r) {
+      roff[(size_t)r] = at;
+      for (int kx = 0; kx < n; ++kx)
+        if (w[(size_t)r * n + kx] > 0.f) cpos[(size_t)r * n + kx] = at++;
+    }
+    roff[(size_t)n / 2 + 1] = at;
+    q_stride = ((size_t)at + 511) / 512 * 512;
+    if (q_stride == 0) q_stride = 512;
+  }
+  std::vector<float> wecm(multi ? (size_t)s_pad * q_stride : 0, 0.f);
   c->ref.assign(n_segments, RefConsts{});
   std::vector<double> e(nh);
   for (int s = 0; s < n_segments; ++s) {
@@ -3703,7 +3881,9 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
         const size_t row = i / n, kx = i % n, tt = kx % (n / 8), mm = kx / (n / 8);
         w2[row * n + tt * 8 + mm] = make_float2(w[i], wec);
       }
-      if (multi) {   // in q's order: bin kx = wl + m (n / 8) of a row at [wl][m]
+      if (multi && compact) {
+        if (cpos[i] >= 0) wecm[(size_t)s * q_stride + (size_t)cpos[i]] = wec;
+      } else if (multi) {   // in q's order: bin kx = wl + m (n / 8) of a row at [wl][m]
         const size_t row = i / n, kx = i % n;
         wecm[(size_t)s * nh + row * n + (kx % (n / 8)) * 8 + kx / (n / 8)] = wec;
       }
@@ -3729,6 +3909,14 @@ int hh_set_reference(hh_ctx* c, const float* images, int n_segments, const uint8
     if ((rcg = ensure_bytes(c, (void**)&c->d_seg_rows, &c->cap_seg_rows, (size_t)(n / 2 + 1) * sizeof(int)))) return rcg;
     HH_HIP(c, hipMemcpyAsync(c->d_seg_rows, seg_rows.data(), seg_rows.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->n_seg_rows = (int)seg_rows.size();
+    if (compact) {
+      if ((rcg = ensure_bytes(c, (void**)&c->d_q_roff, &c->cap_q_roff, roff.size() * sizeof(int)))) return rcg;
+      HH_HIP(c, hipMemcpyAsync(c->d_q_roff, roff.data(), roff.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+      HH_HIP(c, hipStreamSynchronize(c->stream));   // (roff is a local)
+    }
+    if (q_stride != c->q_stride) c->b_pad = 0;   // the buffers of a batch are laid out by it: start over
+    c->q_stride = q_stride;
+    c->q_slices = compact ? (int)(q_stride / 512) : 0;
     if ((rcg = ensure_bytes(c, (void**)&c->d_wec, &c->cap_wec, wecm.size() * sizeof(float)))) return rcg;
     if ((rcg = ensure_bytes(c, (void**)&c->d_ref, &c->cap_ref, (size_t)n_segments * sizeof(RefConsts)))) return rcg;
     HH_HIP(c, hipMemcpyAsync(c->d_wec, wecm.data(), wecm.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
