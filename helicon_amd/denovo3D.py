@@ -56,14 +56,11 @@ def _largest_prime_factor(n: int) -> int:
 
 
 def _image_shape(ny, nx) -> tuple[int, int]:
-    """Validate an image shape for the gfx950 path (``hh_create2``): sides in [8, 1024]; the row transform along
-    the helical axis handles radices 2, 3, 5 and primes up to 31."""
+    """Validate an image shape for the gfx950 path (``hh_create2``): sides in [8, 1024]."""
     ny, nx = int(ny), int(nx)
     if not (_MIN_SIDE <= ny <= _MAX_SIDE and _MIN_SIDE <= nx <= _MAX_SIDE):
         raise ValueError(f"image sides must lie in [{_MIN_SIDE}, {_MAX_SIDE}]; got ({ny}, {nx})")
-    if not (ny == nx and ny in _SUPPORTED_N) and _largest_prime_factor(nx) > 31:
-        raise ValueError(f"nx = {nx} has a prime factor above 31; pad or crop the image along the helical axis")
-    return ny, nx
+    return ny, nx   # (a row length with a prime factor above 31 is served by the direct path: slow, not refused)
 
 
 def _f32(a):

@@ -101,9 +101,10 @@ int hh_selftest_exception(int kind);
 /* device: HIP ordinal; n: image side; max_batch: candidates per launch (0 = default).
  * hh_create2 takes the image's rows and columns (utils.py:31-47 and transforms.py:687-704 accept any (ny, nx); the
  * helical axis runs along the columns).  Square power-of-two sides 32 ... 1024 get the tuned kernels (hh_create(n) is
- * hh_create2(n, n)); every other size in [8, 1024]^2 whose nx has no prime factor above 31 is served by runtime-sized
- * kernels with the same semantics: hh_simulate, hh_power_spectrum, hh_set_reference and the sweeps (candidate lists
- * are swept run by run; tilt = psi = 0), not hh_low_high_pass_filter. */
+ * hh_create2(n, n)); every other size in [8, 1024]^2 is served by runtime-sized kernels with the same semantics:
+ * hh_simulate, hh_power_spectrum, hh_set_reference and the sweeps (candidate lists are swept run by run).  A sweep with
+ * tilt / psi, or on a row length nx with a prime factor above 31 (no row-transform plan), takes the direct path: raster and
+ * float64 direct transforms per candidate — exact, tens of thousands of candidates per second rather than millions. */
 int hh_create(hh_ctx** out, int device, int n, int max_batch);
 int hh_create2(hh_ctx** out, int device, int ny, int nx, int max_batch);
 void hh_destroy(hh_ctx* ctx);
