@@ -104,6 +104,11 @@ EXPORTS = {
     "hh_fused_schedule": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "hh_general_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "hh_affine_transform_2d": (C.c_int, [C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _f32p]),
+    "hh_affine_transform_2d_cubic": (C.c_int, [C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _f32p]),
+    "hh_warp_affine_2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int,
+                                    C.c_void_p]),
+    "hh_rescale_2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hh_helix_moments": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _f64p]),
     "hh_transform_map": (C.c_int, [C.c_int, _f32p, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, _f32p]),
     "hh_apply_helical_symmetry": (C.c_int, [C.c_int, _f32p, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double,

@@ -109,6 +109,9 @@
 #ifndef HH_KF_DEFER_Q
 #define HH_KF_DEFER_Q 1    // fused pass, several segments: the early wavefronts store a candidate's q at the top of the next round
 #endif
+#ifndef HH_KF_EGLOBAL
+#define HH_KF_EGLOBAL 0    // fused pass (N = 512): column factors read straight from global memory (vector L1) instead of LDS copies
+#endif
 #ifndef HH_KF_CUT
 #define HH_KF_CUT 1        // fused pass: part A of a candidate ends after the butterflies of this transform stage
 #endif
@@ -1803,7 +1806,8 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     for (int e = tid; e < n_e4; e += K::THREADS) reinterpret_cast<float4*>(eg)[e] = src[e];
     if (tid < CGS) cgs[tid] = a.cgs[(size_t)b * CGS + tid];
   };
-  stage_factors(cfirst);  // buffer 0
+  constexpr bool EGLOBAL = HH_KF_EGLOBAL && T == 64 && !(HH_KF_SPLIT && N == 1024);
+  if constexpr (!EGLOBAL) stage_factors(cfirst);  // buffer 0
   // Every load issued so far (twiddles, weights, slice, factors) is retired HERE, explicitly: the barrier's fence only
   // waits for LDS traffic, and with register loads still pending at the loop's entry the compiler guards their first
   // uses INSIDE the loop with counted waits — the last of them a vmcnt(0) in the middle of part B, which in every later
@@ -1832,8 +1836,15 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
 
   auto part_a = [&](int cc) {
     const int cur = cc & 1;
-    const float* const egc = eg + (size_t)cur * a.kg * N;
-    const int* const cgc = cgs + cur * CGS;
+    const float* egc;
+    const int* cgc;
+    if constexpr (EGLOBAL) {
+      egc = a.eg + (size_t)(cfirst + cc) * a.kg * N;
+      cgc = a.cgs + (size_t)(cfirst + cc) * CGS;
+    } else {
+      egc = eg + (size_t)cur * a.kg * N;
+      cgc = cgs + cur * CGS;
+    }
     // ---- this group's row of H, built by the group itself into its own exchange buffer (no workgroup barrier).
     // A lane owns two groups of four consecutive columns (x = 4 t + c and 4 (t + T) + c): two independent
     // accumulation chains, and the operands of the next table row are in flight while this row's FMAs issue.
@@ -2069,7 +2080,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     // pass) into the other factor buffer, which nobody reads before the barrier at the end of this round
     // (an explicit s_waitcnt vmcnt(0) ahead of that barrier retires the copies).  One wave-instruction moves
     // 64 x 16 B to a wave-uniform LDS base + lane x 16.
-    const bool more = it + 1 < nc && !(HH_ABLATE & 4096);
+    const bool more = it + 1 < nc && !(HH_ABLATE & 4096) && !EGLOBAL;
     if (more) {
       const size_t bn = (size_t)(cfirst + it + 1);
       const char* const gsrc = reinterpret_cast<const char*>(a.eg + bn * a.kg * N);
@@ -2089,7 +2100,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
     // The LDS-DMA copies of the next candidate's factors count on vmcnt only; neither the workgroup-scope fence nor
     // s_barrier waits for them, so every wavefront retires its own copies before it arrives at the barrier.
     if (more && !(HH_ABLATE & 32768)) lds_dma_wait();
-    if (!(HH_ABLATE & 16384)) __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
+    if (!(HH_ABLATE & 16384) && !EGLOBAL) __syncthreads();  // the next candidate's factors are complete; every group is done reading this one's
   }
   if (late) part_b(nc - 1);
   if (defer_q) flush_q(nc - 1);
@@ -4612,6 +4623,7 @@ int hh_profile_get(hh_ctx* c, hh_profile* out) try {
 
 }  // extern "C"
 
+#include "image_prep.inc"    // pre-sweep image preparation that is scikit-image in the reference (warp, rescale, closing + moments)
 #include "fourier_zoom.inc"  // compute_power_spectra with cutoff_res / output_size: direct non-uniform DFT (hh_power_spectrum_zoom)
 #include "path_a_host.inc"  // Path A: host side and C ABI (hh_pa_*)
 #include "path_a_batch.inc"  // Path A for many candidates at once, device-resident solve (hh_pab_*)

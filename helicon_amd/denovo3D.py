@@ -22,7 +22,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .grid import CandidateGrid, build_grid, radial_band_mask
+from .grid import CandidateGrid, build_grid, radial_band_mask, set_to_periodic_range
 
 __all__ = [
     "SweepEngine",
@@ -37,6 +37,12 @@ __all__ = [
     "threshold_data",
     "apply_helical_symmetry",
     "rotate_shift_image",
+    "transform_image",
+    "rescale",
+    "down_scale",
+    "pad_to_size",
+    "estimate_helix_rotation_center_diameter",
+    "auto_horizontalize",
     "transform_map",
     "is_vertical",
     "units_to_cylindrical",
@@ -516,13 +522,14 @@ def threshold_data(data, thresh_fraction=None, thresh_value=None, *, device=0):
 def rotate_shift_image(data, angle=0, pre_shift=(0, 0), post_shift=(0, 0), rotation_center=None, order=1, *, device=0):
     """``helicon.rotate_shift_image`` (lib/transforms.py:315-369): rotate by ``angle`` degrees about ``rotation_center``
     (default: the pixel (ny // 2, nx // 2)) with (y, x) shifts before and after, resampled as
-    ``scipy.ndimage.affine_transform(order=1, mode="constant")`` does — on the device (``hh_affine_transform_2d``).
+    ``scipy.ndimage.affine_transform(order, mode="constant")`` does — on the device (``hh_affine_transform_2d`` for
+    order 1, the reference's default; ``hh_affine_transform_2d_cubic`` for order 3, what ``auto_horizontalize`` asks for).
     The 2 x 2 matrix and the offset are float32 quantities in the reference; they are formed the same way here."""
     d = np.asarray(data)
     if d.ndim != 2:
         raise ValueError("data must be a 2D image")
-    if order != 1:
-        raise NotImplementedError("the device resampler provides order=1 (the reference's default)")
+    if order not in (1, 3):
+        raise NotImplementedError("the device resampler provides order=1 (the reference's default) and order=3")
     if angle == 0 and pre_shift == [0, 0] and post_shift == [0, 0]:   # (the reference's test: lists only)
         return d * 1.0
     ny, nx = d.shape
@@ -536,8 +543,145 @@ def rotate_shift_image(data, angle=0, pre_shift=(0, 0), post_shift=(0, 0), rotat
     out = np.empty_like(img)
     mat = (C.c_double * 4)(*[float(v) for v in m.ravel()])
     off = (C.c_double * 2)(*[float(v) for v in offset])
-    _lib.check(_lib.lib().hh_affine_transform_2d(int(device), _ptr(img, C.c_float), ny, nx, mat, off, _ptr(out, C.c_float)), None)
+    fn = _lib.lib().hh_affine_transform_2d if order == 1 else _lib.lib().hh_affine_transform_2d_cubic
+    _lib.check(fn(int(device), _ptr(img, C.c_float), ny, nx, mat, off, _ptr(out, C.c_float)), None)
     return out if d.dtype == np.float32 else out.astype(d.dtype if d.dtype.kind == "f" else np.float64)
+
+
+def _float_image(image):
+    """A 2-D image in the floating type scikit-image would compute in (float32 stays, everything else -> float64)."""
+    d = np.asarray(image)
+    if d.ndim != 2:
+        raise ValueError("image must be 2D")
+    return np.ascontiguousarray(d, dtype=np.float32 if d.dtype == np.float32 else np.float64)
+
+
+def _affine_params(scale=(1.0, 1.0), rotation=0.0, translation=(0.0, 0.0)):
+    # skimage.transform.AffineTransform(scale=(sx, sy), rotation, translation=(tx, ty)).params on (x, y, 1) columns
+    sx, sy = scale
+    return np.array([[sx * np.cos(rotation), -sy * np.sin(rotation), translation[0]],
+                     [sx * np.sin(rotation), sy * np.cos(rotation), translation[1]],
+                     [0.0, 0.0, 1.0]])
+
+
+def transform_image(image, scale=1.0, rotation=0.0, rotation_center=None, pre_translation=(0.0, 0.0),
+                    post_translation=(0.0, 0.0), mode="constant", order=1, *, device=0):
+    """``helicon.transform_image`` (lib/transforms.py:238-312): translate, rotate / scale about ``rotation_center``
+    (default (ny / 2, nx / 2)), translate — resampled as ``skimage.transform.warp(image, xform.inverse, mode, order)``
+    does for a 2-D image (its fast path: the image's own floating type, corners outside the image = 0, result clipped
+    to the input's range), on the device (``hh_warp_affine_2d``).  The transforms are composed on the host exactly as
+    the reference composes its ``AffineTransform`` objects (pre_translation -> to centre -> rotation / scale -> back ->
+    post_translation; (y, x) arguments reversed to scikit-image's (x, y)).  Pinned by derivation (scikit-image is not
+    installed beside the reference here): ``oracle/prep.py``."""
+    if mode != "constant":
+        raise NotImplementedError("mode='constant' is provided (the reference's default, and its only use)")
+    if order not in (0, 1):
+        raise NotImplementedError("orders 0 and 1 are provided (1 is the reference's default, and its only use)")
+    img = _float_image(image)
+    centre = np.array(img.shape) / 2.0 if rotation_center is None else np.asarray(rotation_center, dtype=np.float64)
+    sc = np.array((scale, scale), dtype=np.float64) if isinstance(scale, (int, float)) else np.asarray(scale, dtype=np.float64)
+    m = _affine_params(translation=tuple(pre_translation[::-1]))
+    for nxt in (_affine_params(translation=tuple(-centre[::-1])), _affine_params(scale=tuple(sc[::-1]), rotation=np.deg2rad(rotation)),
+                _affine_params(translation=tuple(centre[::-1])), _affine_params(translation=tuple(post_translation[::-1]))):
+        m = nxt @ m   # a + b applies a first
+    inv = np.ascontiguousarray(np.linalg.inv(m), dtype=np.float64)
+    out = np.empty_like(img)
+    _lib.check(_lib.lib().hh_warp_affine_2d(int(device), img.ctypes.data, int(img.dtype == np.float64), img.shape[0], img.shape[1],
+                                            _ptr(inv, C.c_double), int(order), 0.0, 1, out.ctypes.data), None)
+    return out
+
+
+def rescale(image, scale, order=3, anti_aliasing=True, clip=True, *, device=0):
+    """``skimage.transform.rescale(image, scale, order, anti_aliasing)`` of a 2-D image with the defaults the reference
+    leaves alone (mode "reflect", clip) — what the app's binning (app.py:1911-1922) and ``down_scale`` call — on the
+    device (``hh_rescale_2d``): output shape ``max(round(scale * shape), 1)``, a Gaussian of sigma (1 / scale - 1) / 2
+    against aliasing, cubic (or linear) spline zoom on pixel-area coordinates, clip to the input's range."""
+    if order not in (1, 3):
+        raise NotImplementedError("orders 1 and 3 are provided (3 is what the reference asks for)")
+    img = _float_image(image)
+    out_shape = np.maximum(np.round(np.atleast_1d(scale) * np.asarray(img.shape)), 1).astype(int)
+    out = np.empty(tuple(out_shape), dtype=img.dtype)
+    _lib.check(_lib.lib().hh_rescale_2d(int(device), img.ctypes.data, int(img.dtype == np.float64), img.shape[0], img.shape[1],
+                                        int(out_shape[0]), int(out_shape[1]), int(order), int(bool(anti_aliasing)), int(bool(clip)),
+                                        out.ctypes.data), None)
+    return out
+
+
+def pad_to_size(data, shape):
+    """``helicon.pad_to_size`` (lib/transforms.py:441-479) for 2-D images: zero padding, the smaller half first."""
+    d = np.asarray(data)
+    if d.shape == tuple(shape):
+        return d
+    ny, nx = d.shape
+    my, mx = shape
+    yb, xb = max(0, (my - ny) // 2), max(0, (mx - nx) // 2)
+    return np.pad(d, ((yb, max(0, my - yb - ny)), (xb, max(0, mx - xb - nx))), mode="constant")
+
+
+def down_scale(data, target_apix, apix_orig, *, device=0):
+    """``helicon.down_scale`` (lib/filters.py:375-412): resample to a LARGER pixel size (``rescale`` with anti-aliasing,
+    cubic) and pad to even sides; a target at or below the image's own pixel size returns the image unchanged."""
+    if target_apix == apix_orig or target_apix < apix_orig:
+        return data
+    out = rescale(data, apix_orig / target_apix, order=3, anti_aliasing=True, device=device)
+    ny, nx = out.shape
+    return pad_to_size(out, (ny + ny % 2, nx + nx % 2))
+
+
+def estimate_helix_rotation_center_diameter(data, estimate_rotation=True, estimate_center=True, threshold=0, *, device=0):
+    """``helicon.estimate_helix_rotation_center_diameter`` (lib/analysis.py:645-728): the rotation (degrees) that makes
+    the helix horizontal, the vertical shift (pixels) that centres it and its diameter (pixels), from the intensity-
+    weighted second moments of the closed mask ``data > threshold`` — mask, closing and moments on the device
+    (``hh_helix_moments``), the rotation in between with ``transform_image``."""
+    img = _float_image(data)
+    ny, nx = img.shape
+
+    def weighted(im):
+        m = (C.c_double * 8)()
+        _lib.check(_lib.lib().hh_helix_moments(int(device), im.ctypes.data, int(im.dtype == np.float64), ny, nx, float(threshold), m), None)
+        count, cy, _cx, i_yy, i_xx, i_xy, first, last = list(m)
+        if count < 1:
+            return None
+        if count < 2:
+            return 0.0, 0.0, ny
+        angle = np.rad2deg(0.5 * np.arctan2(2.0 * i_xy, i_yy - i_xx)) + 90.0
+        if abs(angle) > 90.0:
+            angle -= 180.0
+        return angle, (ny // 2 - cy) if estimate_center else 0.0, int(last - first + 1)
+
+    first = weighted(img)
+    if first is None:
+        return 0.0, 0.0, ny
+    if estimate_rotation:
+        rotation = set_to_periodic_range(first[0], min=-180, max=180)
+        rotated = transform_image(img, rotation=rotation, device=device)
+    else:
+        rotation, rotated = 0.0, img
+    second = weighted(rotated)
+    if second is None:
+        return rotation, 0.0, ny
+    return rotation, second[1], second[2]
+
+
+def auto_horizontalize(data, refine=False, *, device=0):
+    """``auto_horizontalize`` (webApps/denovo3D/utils.py:383-424): rotate and shift the image so that the helix lies
+    along x through the middle row — the estimate above, optionally refined by a Nelder-Mead search (``scipy.optimize.
+    fmin``, as in the reference) on minus the standard deviation of the mirrored row profile, every evaluation a device
+    resampling; the result resampled with cubic splines."""
+    d = np.asarray(data)
+    work = np.clip(d, 0, None)
+    theta, shift_y, _ = estimate_helix_rotation_center_diameter(d, device=device)
+    if refine:
+        from scipy.optimize import fmin
+
+        def score(x):
+            tmp = rotate_shift_image(work, angle=x[0], post_shift=(x[1], 0), device=device)
+            y = np.sum(tmp, axis=1)[1:]
+            y = y + y[::-1]
+            return -np.std(y)
+
+        theta, shift_y = fmin(score, x0=(theta, shift_y), xtol=1e-2, disp=0)
+    return rotate_shift_image(d, angle=theta, post_shift=(shift_y, 0), order=3, device=device), theta, shift_y
 
 
 def transform_map(data, scale=1.0, rot=0, tilt=0, psi=0, dx=0, dy=0, dz=0, *, device=0):
@@ -663,21 +807,35 @@ _prepared_lock = threading.Lock()
 _PREPARED_MAX = 16
 
 
-def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_diameter, device):
-    """The part of pipeline.py:180-286 the accelerated path provides, on one image: Gaussian low / high
-    pass (pipeline.py:183-188), transpose (:202-203), background subtraction + threshold + /max
-    (:277-284).  Unlike the reference (pipeline.py:282 works in place when no rescale happened) the
-    caller's array is never modified."""
+def _prepare_base(data, apix, low_pass, transpose, horizontalize, device):
+    """``prepare_data`` of pipeline.py:180-208 on one image: Gaussian low / high pass (:183-188), transpose (:202-203),
+    ``auto_horizontalize(refine=True)`` (:204-208).  (The denoisers of :189-201 are scikit-image restoration filters and
+    are refused by the caller.)"""
     if low_pass is not None and low_pass > 2 * apix:
         data = low_high_pass_filter(data, low_pass_fraction=2 * apix / low_pass,
                                     high_pass_fraction=2.0 / np.max(data.shape), device=device)
     if transpose is not None and (transpose > 0 or (transpose < 0 and is_vertical(data))):   # pipeline.py:202-203
         data = data.T
+    if horizontalize:
+        data, _theta, _shift = auto_horizontalize(data, refine=True, device=device)
+    return data
+
+
+def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_diameter, device, horizontalize=0,
+                        target_apix2d=None):
+    """pipeline.py:180-286 on one image: ``prepare_data`` (above), ``down_scale`` to ``target_apix2d`` when that is
+    larger than the image's pixel size (:268-275), background subtraction + threshold + /max (:277-284;
+    ``tube_diameter`` already resolved by the caller).  Unlike the reference (pipeline.py:282 works in place when no
+    rescale happened) the caller's array is never modified."""
+    data = _prepare_base(data, apix, low_pass, transpose, horizontalize, device)
+    ny0 = data.shape[0]
+    a2 = apix if target_apix2d is None or target_apix2d < apix else float(target_apix2d)
+    data = down_scale(data, a2, apix, device=device)
     ny, nx = data.shape
     if thresh_fraction is not None and thresh_fraction >= 0:
-        # pipeline.py:253-255: reconstruct_diameter = tube_diameter if 0 < tube_diameter < ny*apix else ny*apix
-        rec_d = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
-        nr = min(ny // 2 - 1, int(np.ceil(rec_d / 2 / apix) + 1))
+        # pipeline.py:253-255: reconstruct_diameter = tube_diameter if 0 < tube_diameter < ny*apix else ny*apix (BEFORE the rescale)
+        rec_d = tube_diameter if 0 < tube_diameter < ny0 * apix else ny0 * apix
+        nr = min(ny // 2 - 1, int(np.ceil(rec_d / 2 / a2) + 1))
         data = np.asarray(data, dtype=np.float64) - np.median(np.asarray(data)[(ny // 2 - nr, ny // 2 + nr), :])
         data = threshold_data(data, thresh_fraction=thresh_fraction, device=device)
         data = data / np.max(data)
@@ -685,14 +843,17 @@ def _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_d
 
 
 def lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_length, tube_diameter, tube_diameter_inner,
-            reconstruct_length, sym_oversample, return_3d):
-    """The reconstruction box of one task — pipeline.py:242-349 with target_apix2d = apix2d_orig (no rescale), the
-    reference's integer arithmetic: ``(apix3d, D2d, L2d, D3d, D3d_inner, L3d, sym_oversample)``."""
+            reconstruct_length, sym_oversample, return_3d, orig=None):
+    """The reconstruction box of one task — pipeline.py:242-349, the reference's integer arithmetic:
+    ``(apix3d, D2d, L2d, D3d, D3d_inner, L3d, sym_oversample)``.  (ny, nx, apix) describe the image handed to the solver;
+    ``orig`` = (ny, nx, apix) of the image BEFORE ``down_scale`` when the task rescaled it (the tube's length and the
+    reconstruction's diameter / length are worked out on that one, pipeline.py:242-266)."""
     a2 = apix
+    ny0, nx0, a0 = orig if orig is not None else (ny, nx, apix)
     # tube length, reconstruction diameter / length (pipeline.py:242-266)
     if tube_length < 0:
-        tube_length = int(nx * apix) if tube_diameter > ny * apix / 2 else round(np.sqrt((nx * apix) ** 2 / 4 - tube_diameter ** 2 / 4) * 2)
-    rec_d = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
+        tube_length = int(nx0 * a0) if tube_diameter > ny0 * a0 / 2 else round(np.sqrt((nx0 * a0) ** 2 / 4 - tube_diameter ** 2 / 4) * 2)
+    rec_d = tube_diameter if 0 < tube_diameter < ny0 * a0 else ny0 * a0
     rec_d_inner = tube_diameter_inner if 0 < tube_diameter_inner < rec_d else 0
     if reconstruct_length < rise:
         reconstruct_length = max(min(3 * np.max(rise_range), tube_length),
@@ -732,28 +893,32 @@ def lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_leng
 def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
               target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
               reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device, transpose,
-              low_pass):
-    """pipeline.py:242-496 with target_apix2d = apix2d_orig (no rescale): the reconstruction box from the tube's
-    dimensions, ``lsq_reconstruct``, helical symmetrisation back on the input's grid, projections and z sections."""
+              low_pass, horizontalize=0, target_apix2d=None, orig_shape=None):
+    """pipeline.py:242-496: the reconstruction box from the tube's dimensions, ``lsq_reconstruct`` on the (possibly
+    down-scaled) image, helical symmetrisation back on the INPUT's grid, projections and z sections.  ``apix`` is the
+    input's pixel size (apix2d_orig), ``target_apix2d`` the solver image's (>= apix), ``orig_shape`` the image's shape
+    before ``down_scale``."""
     from .solver import lsq_reconstruct
 
     # the image the reference would have at pipeline.py:286 (``prepared`` already went through the low pass, the
-    # transpose and, with thresh_fraction >= 0, the background subtraction + threshold + / max), and its ``data_orig``
+    # transpose, the rescale and, with thresh_fraction >= 0, the background subtraction + threshold + / max), and its
+    # ``data_orig``
     img = np.asarray(prepared)
     ny, nx = img.shape
+    a2 = apix if target_apix2d is None or target_apix2d < apix else float(target_apix2d)
+    ny0, nx0 = orig_shape if orig_shape is not None else (ny, nx)
     if thresh_fraction is not None and thresh_fraction >= 0:
         # data_orig is the image after the in-place median subtraction (pipeline.py:277-282: ``data_orig = data`` aliases it)
-        base = _prepare_task_image(data, apix, low_pass, transpose, None, tube_diameter, device)
-        rec_d0 = tube_diameter if 0 < tube_diameter < ny * apix else ny * apix
-        nr = min(ny // 2 - 1, int(np.ceil(rec_d0 / 2 / apix) + 1))
+        base = _prepare_task_image(data, apix, low_pass, transpose, None, tube_diameter, device, horizontalize, a2)
+        rec_d0 = tube_diameter if 0 < tube_diameter < ny0 * apix else ny0 * apix
+        nr = min(ny // 2 - 1, int(np.ceil(rec_d0 / 2 / a2) + 1))
         data_orig = np.asarray(base) - np.median(np.asarray(base)[(ny // 2 - nr, ny // 2 + nr), :])
         data_orig = data_orig.astype(np.asarray(base).dtype, copy=False)
     else:
         data_orig = img
-    a2 = apix
-    a3, d2, l2, d3, d3_inner, l3, sym_oversample = lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_length,
+    a3, d2, l2, d3, d3_inner, l3, sym_oversample = lsq_box(ny, nx, a2, rise, rise_range, tilt_range, target_apix3d, tube_length,
                                                           tube_diameter, tube_diameter_inner, reconstruct_length, sym_oversample,
-                                                          return_3d)
+                                                          return_3d, orig=(ny0, nx0, apix))
     model = {k: v for k, v in opts.items() if k in ("model", "alpha", "l1_ratio")}   # app.py:2385-2387: model, l1_ratio (+ alpha)
     model.setdefault("model", "lsq")
     (rec3d, set1, set2), score = lsq_reconstruct(
@@ -762,11 +927,11 @@ def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, cs
         reconstruct_diameter_2d_pixel=d2, reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2,
         reconstruct_length_3d_pixel=l3, sym_oversample=sym_oversample, interpolation=interpolation, fsc_test=fsc_test,
         score_metric=score_metric, target_apix2d=a2, algorithm=model, device=device)
-    # the map on the input's grid, at least 1.2 pitches long (pipeline.py:398-417)
+    # the map on the input's grid (its size and pixel size BEFORE any rescale), at least 1.2 pitches long (pipeline.py:398-417)
     tw_eff = twist if abs(twist) < 90 else 180 - abs(twist)
     pitch_pixel = int(360 / abs(tw_eff) * rise / apix + 0.5) if abs(tw_eff) > 1e-2 else int(np.ceil(2 * rise / apix))
-    new_length = max(nx, int(pitch_pixel * 1.2))
-    sym = apply_helical_symmetry(rec3d, a3, twist, rise, csym, new_size=(new_length, ny, ny), new_apix=apix, device=device)
+    new_length = max(nx0, int(pitch_pixel * 1.2))
+    sym = apply_helical_symmetry(rec3d, a3, twist, rise, csym, new_size=(new_length, ny0, ny0), new_apix=apix, device=device)
     tilted = transform_map(sym, scale=1.0, tilt=tilt, psi=psi, dy=dy / apix, device=device)   # pipeline.py:430-432
     x_proj = np.sum(tilted, axis=2).T
     y_proj = np.sum(tilted, axis=1).T
@@ -826,25 +991,40 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
             _blank[dkey] = blank
     if blank:  # pipeline.py:214-218
         return None
-    if denoise or horizontalize:
-        raise NotImplementedError("denoise / horizontalize need scikit-image and are outside the accelerated path")
-    if tube_diameter is not None and tube_diameter < 0:
-        raise NotImplementedError("auto tube diameter (estimate_helix_rotation_center_diameter) needs scikit-image")
+    if denoise:
+        raise NotImplementedError("denoise (scikit-image's restoration filters, pipeline.py:189-201) is outside the accelerated path")
     apix = float(apix2d_orig)
     if target_apix2d is None or target_apix2d < apix:  # pipeline.py:268-269
         target_apix2d = apix
-    if target_apix2d > apix + 1e-9:
-        raise NotImplementedError("down-scaling to target_apix2d > apix2d_orig needs scikit-image's rescale")
+    target_apix2d = float(target_apix2d)
     opts = dict(algorithm or {})
     device = int(opts.get("device", 0))
     mask = opts.get("mask")
     log = bool(opts.get("log", True))
-    pkey = (dkey, apix, None if low_pass is None else float(low_pass), None if transpose is None else int(np.sign(transpose)),
-            None if thresh_fraction is None else float(thresh_fraction), float(tube_diameter), device)
+    bkey = (dkey, apix, None if low_pass is None else float(low_pass), None if transpose is None else int(np.sign(transpose)),
+            bool(horizontalize), device)
+    orig_shape = None
+    if horizontalize or target_apix2d != apix or (tube_diameter is not None and tube_diameter < 0):
+        # the image after prepare_data (pipeline.py:220-231), kept by content: its shape is the "original" one of
+        # pipeline.py:230-231 and the automatic tube diameter is estimated on it (:233-240)
+        with _prepared_lock:
+            base = _prepared.get(("base", bkey))
+        if base is None:
+            base = _prepare_base(data, apix, low_pass, transpose, horizontalize, device)
+            with _prepared_lock:
+                if len(_prepared) >= _PREPARED_MAX:
+                    _prepared.pop(next(iter(_prepared)))
+                _prepared[("base", bkey)] = base
+        orig_shape = tuple(base.shape)
+        if tube_diameter is not None and tube_diameter < 0:
+            _rot, _shift, diameter_px = estimate_helix_rotation_center_diameter(base, device=device)
+            tube_diameter = int(min(orig_shape[0], diameter_px) * apix * 2.5)
+    pkey = (bkey, target_apix2d, None if thresh_fraction is None else float(thresh_fraction), float(tube_diameter))
     with _prepared_lock:
         prepared = _prepared.get(pkey)
     if prepared is None:
-        prepared = _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_diameter, device)
+        prepared = _prepare_task_image(data, apix, low_pass, transpose, thresh_fraction, tube_diameter, device, horizontalize,
+                                       target_apix2d)
         with _prepared_lock:
             if len(_prepared) >= _PREPARED_MAX:
                 _prepared.pop(next(iter(_prepared)))
@@ -853,7 +1033,8 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
         return _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
                          target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
                          reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device,
-                         transpose, low_pass)
+                         transpose, low_pass, horizontalize, target_apix2d, orig_shape)
+    apix = target_apix2d   # the spectrum scorer works on the prepared image's own grid
     ny, nx = _image_shape(*prepared.shape)
     diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))
     ball_radius = float(opts.get("ball_radius", 2.0 * apix))

@@ -14,6 +14,9 @@
  *   hh_apply_helical_symmetry  lib/transforms.py:58-165       apply_helical_symmetry
  *   hh_affine_transform_2d lib/transforms.py:315-369          rotate_shift_image (its scipy.ndimage.affine_transform call)
  *   hh_transform_map       lib/transforms.py:168-235          transform_map (Euler ZYZ + scipy.ndimage.map_coordinates, cubic)
+ *   hh_warp_affine_2d      lib/transforms.py:238-312          transform_image (its skimage.transform.warp call)
+ *   hh_rescale_2d          lib/filters.py:375-412             down_scale, and the app's binning (their skimage rescale call)
+ *   hh_helix_moments       lib/analysis.py:645-728            estimate_helix_rotation_center_diameter (closing + moments)
  *   hh_set_reference +     webApps/denovo3D/app.py:2455-2523  reconstruction_task (the pool over
  *   hh_sweep[_device]                                         candidates) scoring each candidate by
  *                                                             cc(ref[mask], pwr[mask])
@@ -235,6 +238,42 @@ int hh_cosine_similarity_f64(hh_ctx* ctx, const double* a, const double* b, int6
  * (helicon_amd.rotate_shift_image shows it).  Context-free: errors are read with hh_last_error(NULL). */
 int hh_affine_transform_2d(int device, const float* data, int ny, int nx, const double matrix[4], const double offset[2],
                            float* out);
+
+/* The same with order = 3 (auto_horizontalize's last step, webApps/denovo3D/utils.py:420-423:
+ * rotate_shift_image(order = 3)): float64 B-spline prefilter with mirror boundaries, 4 x 4 cubic taps, 0 where the sample
+ * point leaves [0, n - 1]. */
+int hh_affine_transform_2d_cubic(int device, const float* data, int ny, int nx, const double matrix[4], const double offset[2],
+                                 float* out);
+
+/* ---- pre-sweep image preparation that is scikit-image in the reference -------------------------
+ * scikit-image is not installed beside the reference in the build environment: these four are pinned BY DERIVATION
+ * (oracle/prep.py restates scikit-image 0.25's call sequences on the installed SciPy / in NumPy; csrc/image_prep.inc).
+ * `data` / `out` are host rows x cols images, float32 (is_f64 = 0) or float64 (is_f64 = 1) — scikit-image computes in the
+ * image's own floating type, and so do these.  Context-free: errors are read with hh_last_error(NULL).
+ *
+ * hh_warp_affine_2d — skimage.transform.warp(image, inverse_map, order, mode = "constant", cval, clip) of a 2-D image
+ * through its fast path, what helicon.transform_image (lib/transforms.py:238-312) calls: inverse_matrix is the row-major
+ * 3 x 3 matrix that maps OUTPUT (col, row, 1) to INPUT (col, row, w) (helicon_amd.transform_image composes it as the
+ * reference does); order 0 (nearest) or 1 (bilinear); a sample outside the image is cval; clip != 0 clips the result to the
+ * input's range (pixels equal to a cval outside that range keep it). */
+int hh_warp_affine_2d(int device, const void* data, int is_f64, int rows, int cols, const double inverse_matrix[9], int order,
+                      double cval, int clip, void* out);
+
+/* hh_rescale_2d — skimage.transform.rescale / resize(image, (out_rows, out_cols), order, mode = "reflect",
+ * anti_aliasing, clip), what the app's binning (webApps/denovo3D/app.py:1911-1922) and helicon.down_scale
+ * (lib/filters.py:375-412) call: a Gaussian of sigma = max(0, (rows / out_rows - 1) / 2) per axis (scipy.ndimage.gaussian_filter,
+ * truncate 4, mirror boundaries) when anti_aliasing != 0, then scipy.ndimage.zoom(order, mode = "mirror", grid_mode = True)
+ * — order 3 on the float64 mirror-prefiltered image, order 1 on the image itself —, then the clip to the input's range.
+ * The caller computes (out_rows, out_cols) = max(round(scale * shape), 1) as rescale does. */
+int hh_rescale_2d(int device, const void* data, int is_f64, int rows, int cols, int out_rows, int out_cols, int order,
+                  int anti_aliasing, int clip, void* out);
+
+/* hh_helix_moments — the numeric part of helicon.estimate_helix_rotation_center_diameter (lib/analysis.py:645-728):
+ * mask = skimage.morphology.closing(data > threshold, mode = "ignore") (3 x 3 cross: a dilation, then an erosion, both
+ * ignoring what lies outside the image), then _weighted_params over the mask in float64 with w = I - min_mask(I) + 1e-8.
+ * out = {pixels in the mask, c_y, c_x, i_yy, i_xx, i_xy, first mask row, last mask row}; with an empty mask out[0] = 0 and
+ * the rest is not meaningful. */
+int hh_helix_moments(int device, const void* data, int is_f64, int rows, int cols, double threshold, double out[8]);
 
 /* helicon.transform_map (lib/transforms.py:168-235; the reference's task function resamples the symmetrised map with
  * it when tilt / psi / dy are not zero, pipeline.py:430-432): data is host float32 [shape[0]][shape[1]][shape[2]] (z, y, x);

@@ -406,6 +406,36 @@ def g8_rotate_shift():
     print("g8_rotate_shift", len(cases))
 
 
+def g15_rotate_shift_cubic():
+    """helicon.rotate_shift_image(order=3) (lib/transforms.py:315-369: scipy affine_transform, cubic spline, constant) — what
+    auto_horizontalize's last step calls (webApps/denovo3D/utils.py:420-423) —, helicon.pad_to_size (lib/transforms.py:441-479)
+    and helicon.set_to_periodic_range (lib/angular.py:84-108)."""
+    rng = np.random.default_rng(15)
+    out = {}
+    cases = [
+        (32, 48, 7.5, (0, 0), (0, 0)),
+        (48, 32, -33.0, (1.5, -2.0), (0.25, 3.0)),
+        (40, 40, 90.0, (0, 0), (2, -1)),
+        (64, 64, 0.0, (0, 0), (-4.3, 0)),
+        (25, 31, 1.75, (0, 0), (2.125, 0)),
+    ]
+    for k, (ny, nx, ang, pre, post) in enumerate(cases):
+        img = rng.normal(size=(ny, nx)).astype(np.float32)
+        got = transforms.rotate_shift_image(img, angle=ang, pre_shift=pre, post_shift=post, order=3)
+        out[f"case{k}_image"] = img
+        out[f"case{k}_args"] = np.array([ang, *pre, *post], dtype=np.float64)
+        out[f"case{k}_out"] = np.asarray(got)
+    for k, (shape, target) in enumerate([((5, 7), (8, 8)), ((6, 6), (6, 6)), ((7, 9), (8, 10)), ((4, 4), (7, 5))]):
+        img = rng.normal(size=shape).astype(np.float32)
+        out[f"pad{k}_image"] = img
+        out[f"pad{k}_out"] = np.asarray(transforms.pad_to_size(img, target))
+    vals = np.array([-540.0, -181.0, -180.0, -90.5, 0.0, 179.9, 180.0, 180.1, 271.0, 725.0])
+    out["periodic_in"] = vals
+    out["periodic_out"] = np.array([angular.set_to_periodic_range(float(v), min=-180, max=180) for v in vals])
+    np.savez_compressed(OUT / "g15_rotate_shift_cubic.npz", **out)
+    print("g15_rotate_shift_cubic", len(cases))
+
+
 def g9_process_one_task():
     """The reference's own task function (webApps/denovo3D/pipeline.py:84-496) on a small helix, in the configuration the
     GPU build reproduces end to end: no rescale (target_apix2d = apix2d_orig), no tilt / psi / dy, model "lsq"."""
@@ -575,7 +605,7 @@ def g14_sklearn_models():
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random,
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random, g15_rotate_shift_cubic,
               g14_sklearn_models]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:

@@ -1,0 +1,162 @@
+"""Pre-sweep image preparation that is scikit-image in the reference, on the device through the C ABI
+(csrc/image_prep.inc) against oracle/prep.py — scikit-image's call sequences restated on the installed SciPy (pinned by
+derivation: scikit-image itself is not installed beside the reference) — and, where the reference function needs SciPy only
+(``rotate_shift_image(order=3)``), against the reference's own outputs (fixture G15)."""
+import numpy as np
+import pytest
+
+import helicon_amd as H
+from helicon_amd import denovo3D as D
+from oracle import path_b as O
+from oracle import prep as P
+from tests.test_oracle_prep import _helix_image
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rotate_shift_image_cubic_reproduces_the_reference(golden_dir):
+    g = np.load(golden_dir / "g15_rotate_shift_cubic.npz")
+    for k in range(5):
+        a = g[f"case{k}_args"]
+        got = H.rotate_shift_image(g[f"case{k}_image"], a[0], (a[1], a[2]), (a[3], a[4]), order=3)
+        want = g[f"case{k}_out"]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        np.testing.assert_array_equal(got == 0, want == 0)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    big = np.random.default_rng(3).normal(size=(300, 420)).astype(np.float32)
+    np.testing.assert_allclose(H.rotate_shift_image(big, 17.0, (2.5, -1.0), (0.0, 4.0), order=3),
+                               P.rotate_shift_image(big, 17.0, (2.5, -1.0), (0.0, 4.0), order=3), rtol=0, atol=5e-6)
+    for k, target in enumerate([(8, 8), (6, 6), (8, 10), (7, 5)]):
+        np.testing.assert_array_equal(D.pad_to_size(g[f"pad{k}_image"], target), g[f"pad{k}_out"])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_transform_image_against_the_oracle(dtype):
+    """helicon.transform_image = skimage's fast warp, in the image's own floating type: rotations, scales (also
+    anisotropic), both translations, an off-centre rotation centre, a rectangle; nearest and bilinear."""
+    rng = np.random.default_rng(11)
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    cases = [
+        ((64, 64), dict(rotation=10.0)),
+        ((48, 80), dict(rotation=-37.5, post_translation=(2.5, -1.25))),
+        ((80, 48), dict(rotation=90.0, pre_translation=(1.0, 0.5), post_translation=(0.0, 3.0))),
+        ((57, 91), dict(scale=1.3, rotation=5.0)),
+        ((64, 96), dict(scale=(0.8, 1.25), rotation=-12.0, rotation_center=(20.0, 50.5))),
+        ((40, 40), dict(post_translation=(3.0, 0.0))),
+        ((40, 40), dict()),
+        ((33, 47), dict(rotation=181.0, order=0)),
+    ]
+    for shape, kw in cases:
+        img = rng.normal(size=shape).astype(dtype)
+        got = H.denovo3D.transform_image(img, **kw)
+        want = P.transform_image(img, **kw)
+        assert got.shape == want.shape and got.dtype == want.dtype == dtype
+        bad = np.abs(got.astype(np.float64) - want) > tol
+        # (a sample that lands within rounding of a pixel boundary may take the neighbouring cell in float32)
+        assert bad.mean() <= (2e-4 if dtype == np.float32 else 0), (shape, kw, float(bad.mean()))
+    # the clip: a constant image shifted — the rows that come from outside keep cval = 0 although 0 < min
+    flat = np.full((16, 16), 5.0, dtype=dtype)
+    np.testing.assert_array_equal(H.denovo3D.transform_image(flat, post_translation=(3.0, 0.0)),
+                                  P.transform_image(flat, post_translation=(3.0, 0.0)))
+    with pytest.raises(NotImplementedError):
+        H.denovo3D.transform_image(flat, order=3)
+    with pytest.raises(NotImplementedError):
+        H.denovo3D.transform_image(flat, mode="edge")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rescale_and_down_scale_against_the_oracle(dtype):
+    """skimage.transform.rescale as the app's binning (app.py:1911-1922) and helicon.down_scale (filters.py:375-412) call
+    it: Gaussian anti-aliasing, cubic spline zoom on pixel-area coordinates, clip; binning factors, a pixel-size ratio that
+    rounds, odd sides, a rectangle, up-scaling, the linear order, no anti-aliasing."""
+    rng = np.random.default_rng(12)
+    tol = 3e-6 if dtype == np.float32 else 1e-11
+    for shape, scale, kw in [((64, 64), 0.5, {}), ((90, 120), 1 / 3, {}), ((75, 101), 0.37, {}), ((128, 96), 0.25, {}),
+                             ((50, 70), 1 / 2.7, {}), ((40, 40), 1.0, {}), ((24, 36), 1.5, {}), ((64, 64), 0.5, dict(order=1)),
+                             ((64, 80), 0.4, dict(anti_aliasing=False)), ((5, 5), 0.5, {}), ((200, 300), 0.2, {})]:
+        img = (rng.random(shape) * 3 - 1).astype(dtype)
+        got = D.rescale(img, scale, **kw)
+        want = P.rescale(img, scale, **kw)
+        assert got.shape == want.shape and got.dtype == want.dtype == dtype, (shape, scale)
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=str((shape, scale, kw)))
+    img = (rng.random((50, 70)) * 3 - 1).astype(dtype)
+    for target in (2.7, 3.0, 1.0, 0.5):
+        got, want = D.down_scale(img, target, 1.0), P.down_scale(img, target, 1.0)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    assert D.down_scale(img, 1.0, 1.0) is img
+    smooth = np.linspace(0, 1, 64 * 64, dtype=dtype).reshape(64, 64)
+    assert D.rescale(smooth, 0.5).min() >= smooth.min() and D.rescale(smooth, 0.5).max() <= smooth.max()   # the clip
+
+
+def test_helix_estimates_against_the_oracle():
+    """helicon.estimate_helix_rotation_center_diameter: closing + weighted moments on the device, the rotation in between
+    with transform_image; and auto_horizontalize with and without the Nelder-Mead refinement."""
+    for angle, shift, seed in [(12.0, 5.0, 0), (-25.0, -3.0, 1), (0.0, 0.0, 2), (3.5, -8.0, 3)]:
+        img = _helix_image(angle=angle, shift=shift, seed=seed)
+        got = D.estimate_helix_rotation_center_diameter(img)
+        want = P.estimate_helix_rotation_center_diameter(img)
+        assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-4 and got[2] == want[2], (got, want)
+        got = D.estimate_helix_rotation_center_diameter(img, estimate_rotation=False, estimate_center=False, threshold=0.2)
+        want = P.estimate_helix_rotation_center_diameter(img, estimate_rotation=False, estimate_center=False, threshold=0.2)
+        assert got == pytest.approx(want, abs=1e-9)
+        out, theta, sy = D.auto_horizontalize(img)
+        out_w, theta_w, sy_w = P.auto_horizontalize(img)
+        assert abs(theta - theta_w) < 1e-6 and abs(sy - sy_w) < 1e-4
+        np.testing.assert_allclose(out, out_w, rtol=0, atol=2e-4)
+    # float64 input, nothing above the threshold, a single pixel
+    assert D.estimate_helix_rotation_center_diameter(np.zeros((16, 20))) == (0.0, 0.0, 16)
+    one = np.zeros((16, 20), np.float32)
+    one[5, 7] = 1.0
+    assert D.estimate_helix_rotation_center_diameter(one) == P.estimate_helix_rotation_center_diameter(one)
+    img = _helix_image(angle=7.0, shift=4.0, seed=5)
+    out, theta, sy = D.auto_horizontalize(img, refine=True)
+    out_w, theta_w, sy_w = P.auto_horizontalize(img, refine=True)
+    # (a simplex search: the two runs see scores that differ in the last float32 bits, so the end points agree to the
+    # search's own tolerance, xtol = 1e-2, not to rounding)
+    assert abs(theta - theta_w) < 0.05 and abs(sy - sy_w) < 0.05, (theta, theta_w, sy, sy_w)
+    assert O.cross_correlation_coefficient(out, out_w) > 0.999
+
+
+def _task_args(data, twist, rise, *, apix=5.0, target_apix2d=5.0, horizontalize=0, tube_diameter=None, thresh_fraction=-1,
+               low_pass=0, algorithm=None):
+    ny, nx = data.shape
+    tube_diameter = 0.4 * ny * apix if tube_diameter is None else tube_diameter
+    return (0, 1, data, None, 0, twist, rise, (rise, rise), 1, 0.0, (0, 0), 0.0, (0, 0), 0.0, (0, 0),
+            apix, "", low_pass, 0, horizontalize, 5.0, target_apix2d, thresh_fraction, -1, nx * apix, tube_diameter, 0,
+            -1, -1, "linear", 0, 0, "cosine", algorithm or {}, 0, 1)
+
+
+def test_process_one_task_prepares_the_image_like_the_reference_pipeline():
+    """pipeline.py:180-286 with the steps that used to be refused: down_scale to target_apix2d > apix2d_orig, the automatic
+    tube diameter (tube_diameter < 0), auto_horizontalize — the image the task hands on (third tuple, first entry) against
+    the same steps through the oracle."""
+    apix = 2.0
+    img = _helix_image(ny=128, nx=192, angle=0.0, shift=0.0, seed=7)
+    # down-scale 2 -> 5 A/pixel, background / threshold on the rescaled image
+    res = H.process_one_task(*_task_args(img, 29.0, 25.0, apix=apix, target_apix2d=5.0, thresh_fraction=0.1))
+    want = P.down_scale(img, 5.0, apix)
+    ny, nx = want.shape
+    assert res[2][0].shape == (ny, nx) == (52, 78) and res[2][4] == 5.0
+    rec_d = 0.4 * 128 * apix
+    nr = min(ny // 2 - 1, int(np.ceil(rec_d / 2 / 5.0) + 1))
+    w = want.astype(np.float64) - np.median(want[(ny // 2 - nr, ny // 2 + nr), :])
+    w = O.threshold_data(w, thresh_fraction=0.1)
+    np.testing.assert_allclose(res[2][0], w / w.max(), rtol=0, atol=2e-5)
+    assert np.isfinite(res[0])
+    # automatic tube diameter: int(min(ny, diameter) * apix * 2.5) of the estimate (pipeline.py:233-240) sets the default
+    # helical diameter of the spectrum scorer
+    auto = H.process_one_task(*_task_args(img, 29.0, 25.0, apix=apix, target_apix2d=apix, tube_diameter=-1))
+    d_px = P.estimate_helix_rotation_center_diameter(img)[2]
+    fixed = H.process_one_task(*_task_args(img, 29.0, 25.0, apix=apix, target_apix2d=apix,
+                                           tube_diameter=int(min(128, d_px) * apix * 2.5)))
+    assert auto[0] == fixed[0]
+    # horizontalize: the pipeline's auto_horizontalize(refine=True) in front of everything else
+    tilted = _helix_image(ny=128, nx=192, angle=4.0, shift=3.0, seed=8)
+    res = H.process_one_task(*_task_args(tilted, 29.0, 25.0, apix=apix, target_apix2d=apix, horizontalize=1))
+    want, _, _ = P.auto_horizontalize(tilted, refine=True)
+    assert O.cross_correlation_coefficient(res[2][0], want) > 0.999
+    with pytest.raises(NotImplementedError):
+        bad = list(_task_args(img, 29.0, 25.0))
+        bad[16] = "wavelet"
+        H.process_one_task(*bad)

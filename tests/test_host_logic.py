@@ -285,8 +285,13 @@ def test_process_one_task_host_logic_with_a_stub_engine(tmp_path, monkeypatch):
     assert stub.ref_calls == calls + 1          # stack[0] was last seen two references ago: one new upload, then cached
     D.process_one_task(*_task(img, 29.0, 25.0, target_apix2d=2.0))                  # finer than the image: no rescale
     assert stub.ref_calls == calls + 1
-    with pytest.raises(NotImplementedError):
-        D.process_one_task(*_task(img, 29.0, 25.0, target_apix2d=10.0))             # needs skimage.rescale
+    # coarser than the image: down_scale runs on the device (hh_rescale_2d) — without one that is a loud error, not a fallback
+    with pytest.raises(H.HeliconHipError, match="no such HIP device"):
+        D.process_one_task(*_task(img, 29.0, 25.0, target_apix2d=10.0))
+    with monkeypatch.context() as mp:
+        mp.setattr(D, "down_scale", lambda d, target, orig, device=0: np.asarray(d)[::2, ::2] * 1.0)
+        out = D.process_one_task(*_task(img, 29.0, 25.0, target_apix2d=10.0))
+        assert out[2][0].shape == (8, 8) and out[2][4] == 10.0                      # the prepared image and ITS pixel size
     t = list(_task(img, 29.0, 25.0))
     t[16] = "tv"
     with pytest.raises(NotImplementedError):
