@@ -19,8 +19,9 @@ KW = dict(reconstruct_diameter_2d_pixel=20, reconstruct_diameter_3d_pixel=20, re
           reconstruct_length_3d_pixel=6, sym_oversample=1)
 DEFAULTS = {"elasticnet": (1e-4, 0.5, False), "lasso": (1e-4, 1.0, False), "ridge": (1.0, 0.0, True), "lreg": (0.0, 0.0, False)}
 # what separates the device's float64 minimiser from the reference's float32, loosely converged number (see the module text;
-# ridge: the reference stops L-BFGS-B at tol 1e-2 — its trilinear result is 2.8e-3 below the minimiser's score)
-TOL = {"elasticnet": 5e-4, "lasso": 5e-4, "ridge": 5e-3, "lreg": 1e-4}
+# ridge: the reference stops L-BFGS-B at tol 1e-2 — its trilinear results are 2.8e-3 ... 5.9e-3 (twist 33) below the
+# minimiser's score; the objective test below is what says which of the two is the minimiser)
+TOL = {"elasticnet": 5e-4, "lasso": 5e-4, "ridge": 1e-2, "lreg": 1e-4}
 
 
 def _objective(parts, x, alpha, rho, ridge_form):
