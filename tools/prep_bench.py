@@ -44,3 +44,35 @@ for n in [int(a) for a in sys.argv[1:]] or [512, 1024]:
                 "are four launches of N/2..N/2+1 single-transform workgroups",
     }), flush=True)
     eng.close()
+
+# ---- round 4: the scikit-image part of the preparation (csrc/image_prep.inc) against oracle/prep.py on the host ------------------
+from helicon_amd import denovo3D as D  # noqa: E402
+from oracle import prep as P  # noqa: E402  (CPU baseline and checker only)
+
+
+def _timed(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return 1e3 * (time.perf_counter() - t0) / reps, out
+
+
+for ny, nx in [(256, 512), (512, 1024)]:
+    yy, xx = np.mgrid[0:ny, 0:nx].astype(np.float64)
+    a = np.deg2rad(6.0)
+    dist = -(xx - nx / 2) * np.sin(a) + (yy - ny / 2 - 4.0) * np.cos(a)
+    img = (np.exp(-0.5 * (dist / (ny / 12)) ** 2) * (np.abs(dist) < ny / 5) * (1 + 0.05 * np.random.default_rng(1).random((ny, nx)))).astype(np.float32)
+    row = {"op": "scikit-image part of the image preparation", "shape": [ny, nx]}
+    for name, dev, cpu in [
+        ("down_scale_x0.4", lambda: D.down_scale(img, 2.5, 1.0), lambda: P.down_scale(img, 2.5, 1.0)),
+        ("transform_image_rot7", lambda: D.transform_image(img, rotation=7.0, post_translation=(3.0, 0.0)),
+         lambda: P.transform_image(img, rotation=7.0, post_translation=(3.0, 0.0))),
+        ("estimate_helix", lambda: D.estimate_helix_rotation_center_diameter(img), lambda: P.estimate_helix_rotation_center_diameter(img)),
+        ("rotate_shift_cubic", lambda: D.rotate_shift_image(img, 7.0, (0, 0), (3.0, 0), order=3), lambda: P.rotate_shift_image(img, 7.0, (0, 0), (3.0, 0), order=3)),
+    ]:
+        g_ms, g = _timed(dev, 20)
+        c_ms, c = _timed(cpu, 3)
+        err = float(np.abs(np.asarray(g, dtype=np.float64) - np.asarray(c, dtype=np.float64)).max())
+        row[name] = {"device_ms_host_to_host": round(g_ms, 3), "scipy_numpy_ms_1core": round(c_ms, 3), "max_abs_diff": err}
+    print(json.dumps(row), flush=True)
