@@ -175,6 +175,47 @@ def g3b_general_sizes():
     np.savez_compressed(OUT / "g3b_general_sizes.npz", **arrs)
 
 
+def g3c_general_sizes_tilted():
+    """G3b's composition with an out-of-plane tilt, an in-plane rotation and a shift (utils.py:31-47, 166-170 take any
+    (ny, nx) with any tilt / psi / dy): scores of a small twist-major grid on 80 x 120 and on 48 x 74 (a row length with
+    the prime factor 37), log spectrum, and one simulated projection per size."""
+    arrs = {}
+    tags = []
+    for ny, nx, apix, truth, twists, rises, tilt, psi, dy in (
+        (80, 120, 2.0, (-40.0, 7.0, 2), np.arange(-42.0, -38.0 + 0.5, 1.0), np.arange(6.0, 8.0 + 0.25, 0.5), 5.0, 10.0, 2.0),
+        (48, 74, 2.5, (29.0, 10.0, 1), np.arange(27.0, 31.0 + 0.5, 1.0), np.arange(9.0, 11.0 + 0.25, 0.5), -4.0, 3.0, -1.5),
+    ):
+        tw0, rs0, cs0 = truth
+        d = 0.4 * ny * apix
+        br = 2 * apix
+        kw = dict(tilt=tilt, psi=psi, dy=dy)
+        clean = utils.simulate_helical_projection(1, tw0, rs0, cs0, d, br, 0, 0, ny, nx, apix, **kw)
+        noise = np.random.default_rng(2).normal(0, 0.5 * clean.std(), clean.shape)
+        img = (clean + noise).astype(np.float32)
+        ky = np.arange(ny) - ny // 2
+        kx = np.arange(nx) - nx // 2
+        r2 = ky[:, None].astype(np.float64) ** 2 + kx[None, :].astype(np.float64) ** 2
+        mask = (r2 > 4.0) & (r2 < (min(ny, nx) // 2 - 1) ** 2)
+        tag = f"s{ny}x{nx}"
+        tags.append(tag)
+        arrs[f"{tag}_clean"] = clean.astype(np.float32)
+        arrs[f"{tag}_image"] = img
+        arrs[f"{tag}_meta"] = np.asarray([ny, nx, apix, tw0, rs0, cs0, d, br, tilt, psi, dy], dtype=np.float64)
+        arrs[f"{tag}_twists"] = twists
+        arrs[f"{tag}_rises"] = rises
+        pe = _pwr(img.astype(np.float64), True)
+        sc = np.zeros((len(twists), len(rises)))
+        for i, tw in enumerate(twists):
+            for j, rs in enumerate(rises):
+                sim = utils.simulate_helical_projection(1, float(tw), float(rs), cs0, d, br, 0, 0, ny, nx, apix, **kw)
+                sc[i, j] = analysis.cross_correlation_coefficient(pe[mask], _pwr(sim, True)[mask])
+        arrs[f"{tag}_scores_log1"] = sc
+        arrs[f"{tag}_argmax_log1"] = np.asarray(np.unravel_index(np.argmax(sc), sc.shape))
+    arrs["tags"] = np.asarray(tags)
+    np.savez_compressed(OUT / "g3c_general_sizes_tilted.npz", **arrs)
+    print("g3c_general_sizes_tilted", tags)
+
+
 def g4_path_a():
     """Path A building blocks: mask counts, symmetry-pair lists, Halton index lists,
     back-projected coordinates, and the CSR triplets of the NN data matrix and of the NN symmetry matrix on the inputs of
@@ -604,7 +645,7 @@ def g14_sklearn_models():
 
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
-    makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
+    makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g3c_general_sizes_tilted, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
               g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random, g15_rotate_shift_cubic,
               g14_sklearn_models]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
