@@ -548,12 +548,16 @@ def rotate_shift_image(data, angle=0, pre_shift=(0, 0), post_shift=(0, 0), rotat
     return out if d.dtype == np.float32 else out.astype(d.dtype if d.dtype.kind == "f" else np.float64)
 
 
-def _float_image(image):
-    """A 2-D image in the floating type scikit-image would compute in (float32 stays, everything else -> float64)."""
+def _float_image(image, integers_as_values=False):
+    """A 2-D image in the floating type scikit-image would compute in (float32 stays, float16 -> float32, float64 stays).
+    scikit-image rescales INTEGER images to [0, 1] (``img_as_float``) before it resamples them; that convention is not
+    reproduced — integer images are refused unless the caller's result does not depend on a scale of the intensities."""
     d = np.asarray(image)
     if d.ndim != 2:
         raise ValueError("image must be 2D")
-    return np.ascontiguousarray(d, dtype=np.float32 if d.dtype == np.float32 else np.float64)
+    if d.dtype.kind != "f" and not integers_as_values:
+        raise TypeError("a floating-point image is expected (scikit-image would rescale an integer image to [0, 1] first: convert it)")
+    return np.ascontiguousarray(d, dtype=np.float32 if d.dtype in (np.float32, np.float16) else np.float64)
 
 
 def _affine_params(scale=(1.0, 1.0), rotation=0.0, translation=(0.0, 0.0)):
@@ -633,7 +637,7 @@ def estimate_helix_rotation_center_diameter(data, estimate_rotation=True, estima
     the helix horizontal, the vertical shift (pixels) that centres it and its diameter (pixels), from the intensity-
     weighted second moments of the closed mask ``data > threshold`` — mask, closing and moments on the device
     (``hh_helix_moments``), the rotation in between with ``transform_image``."""
-    img = _float_image(data)
+    img = _float_image(data, integers_as_values=True)   # (rotation, centre and extent do not depend on the intensity scale)
     ny, nx = img.shape
 
     def weighted(im):
@@ -893,7 +897,7 @@ def lsq_box(ny, nx, apix, rise, rise_range, tilt_range, target_apix3d, tube_leng
 def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
               target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
               reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device, transpose,
-              low_pass, horizontalize=0, target_apix2d=None, orig_shape=None):
+              low_pass, horizontalize=0, target_apix2d=None, orig_shape=None, psi_range=0, dy_range=0):
     """pipeline.py:242-496: the reconstruction box from the tube's dimensions, ``lsq_reconstruct`` on the (possibly
     down-scaled) image, helical symmetrisation back on the INPUT's grid, projections and z sections.  ``apix`` is the
     input's pixel size (apix2d_orig), ``target_apix2d`` the solver image's (>= apix), ``orig_shape`` the image's shape
@@ -921,18 +925,33 @@ def _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, cs
                                                           return_3d, orig=(ny0, nx0, apix))
     model = {k: v for k, v in opts.items() if k in ("model", "alpha", "l1_ratio")}   # app.py:2385-2387: model, l1_ratio (+ alpha)
     model.setdefault("model", "lsq")
+    # the local refinement's ranges (pipeline.py:357-369): only for the models that have it, only where a range is open
+    refine_range = None
+    if model.get("model", "lsq") in ("lsq", "elasticnet", "lasso", "ridge"):
+        r_dict = {}
+        if tilt_range is not None and tilt_range[1] > tilt_range[0]:
+            r_dict["tilt"] = max(abs(tilt_range[0]), abs(tilt_range[1]))
+        for name, rng in (("psi", psi_range), ("dy", dy_range)):
+            width = float(np.max(np.abs(rng))) if rng is not None else 0.0   # (the app passes scalars; a (lo, hi) pair is read as its extent)
+            if width > 0:
+                r_dict[name] = width
+        refine_range = r_dict or None
+    lsq_reconstruct._refined_params = {}
     (rec3d, set1, set2), score = lsq_reconstruct(
         img, a2 / a3, twist, rise / a3, csym, tilt, psi, dy / a2, thresh_fraction=thresh_fraction,
         positive_constraint=positive_constraint, reconstruct_diameter_3d_inner_pixel=d3_inner,
         reconstruct_diameter_2d_pixel=d2, reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2,
         reconstruct_length_3d_pixel=l3, sym_oversample=sym_oversample, interpolation=interpolation, fsc_test=fsc_test,
-        score_metric=score_metric, target_apix2d=a2, algorithm=model, device=device)
+        score_metric=score_metric, target_apix2d=a2, algorithm=model, refine_tilt_psi_dy_range=refine_range, device=device)
+    refined = getattr(lsq_reconstruct, "_refined_params", {}) or {}   # pipeline.py:419-428: refined angles for the projections, consumed once
+    lsq_reconstruct._refined_params = {}
+    tilt_viz, psi_viz, dy_viz = refined.get("tilt", tilt), refined.get("psi", psi), refined.get("dy", dy)
     # the map on the input's grid (its size and pixel size BEFORE any rescale), at least 1.2 pitches long (pipeline.py:398-417)
     tw_eff = twist if abs(twist) < 90 else 180 - abs(twist)
     pitch_pixel = int(360 / abs(tw_eff) * rise / apix + 0.5) if abs(tw_eff) > 1e-2 else int(np.ceil(2 * rise / apix))
     new_length = max(nx0, int(pitch_pixel * 1.2))
     sym = apply_helical_symmetry(rec3d, a3, twist, rise, csym, new_size=(new_length, ny0, ny0), new_apix=apix, device=device)
-    tilted = transform_map(sym, scale=1.0, tilt=tilt, psi=psi, dy=dy / apix, device=device)   # pipeline.py:430-432
+    tilted = transform_map(sym, scale=1.0, tilt=tilt_viz, psi=psi_viz, dy=dy_viz / apix, device=device)   # pipeline.py:430-432
     x_proj = np.sum(tilted, axis=2).T
     y_proj = np.sum(tilted, axis=1).T
     y_max = y_proj.max()
@@ -1033,7 +1052,7 @@ def process_one_task(ti, ntasks, data, imageFile, imageIndex, twist, rise, rise_
         return _task_lsq(data, prepared, imageFile, imageIndex, twist, rise, rise_range, csym, tilt, tilt_range, psi, dy, apix,
                          target_apix3d, thresh_fraction, positive_constraint, tube_length, tube_diameter, tube_diameter_inner,
                          reconstruct_length, sym_oversample, interpolation, fsc_test, return_3d, score_metric, opts, device,
-                         transpose, low_pass, horizontalize, target_apix2d, orig_shape)
+                         transpose, low_pass, horizontalize, target_apix2d, orig_shape, psi_range, dy_range)
     apix = target_apix2d   # the spectrum scorer works on the prepared image's own grid
     ny, nx = _image_shape(*prepared.shape)
     diameter = float(opts.get("helical_diameter", 0.4 * (tube_diameter if tube_diameter > 0 else ny * apix)))

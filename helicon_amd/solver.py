@@ -13,10 +13,12 @@ What runs where:
 * ``hh_pa_*`` (csrc/path_a.inc): the single-candidate projector, kept for trilinear candidates with tilt / psi (rays that
   cross cell layers) — products on the device, the trust-region glue of this module on the host — and as the parity
   reference of the group solver's products;
+* ``refine_tilt_psi_dy`` (:550-841, switched on by ``refine_tilt_psi_dy_range``, :384-439): the Gauss-Newton loop of the
+  reference with every matrix an ``hh_pa`` operator on the device and SciPy's own ``lsq_linear`` / ``lsqr`` driving them;
 * this module: argument handling, the positivity rule (:352-355), grouping, half sets, the volume assembly (:532-547).
 
-Not provided (``NotImplementedError``): model "ard", tilt / psi / dy refinement, scores other than cosine.  There is no CPU
-fallback: without the library or a GPU the call raises.
+Not provided (``NotImplementedError``): model "ard", scores other than cosine.  There is no CPU fallback: without the
+library or a GPU the call raises.
 """
 from __future__ import annotations
 
@@ -667,6 +669,92 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
     return out
 
 
+def refine_tilt_psi_dy(projection_image, scale2d_to_3d, twist_degree, rise_pixel, csym, reconstruct_diameter_2d_pixel,
+                       reconstruct_length_2d_pixel, reconstruct_diameter_3d_pixel, reconstruct_diameter_3d_inner_pixel,
+                       reconstruct_length_3d_pixel, sym_oversample, interpolation, x_init, tilt_0=0.0, psi_0=0.0, dy_0=0.0,
+                       delta_tilt=0.5, delta_psi=1.0, delta_dy=0.2, max_iter=5, tol_tilt=0.05, tol_psi=0.1, tol_dy=0.05,
+                       bounds_tilt=(-30.0, 30.0), bounds_psi=(-45.0, 45.0), bounds_dy=(-5.0, 5.0), positive_constraint=-1,
+                       algorithm=None, verbose=0, cpu=1, *, device=0):
+    """solver_linear_regression.py:550-841: Gauss-Newton refinement of (tilt, psi, dy) with a finite-difference Jacobian of
+    the predicted projection.  Returns ``(tilt, psi, dy, x, cosine score)``.
+
+    Every matrix of the reference is an implicit operator on the device here (``hh_pa``, one per geometry: the general
+    projector with tilt and psi); what drives them is the reference's own driver — ``scipy.optimize.lsq_linear(bounds=(0,
+    max b), max_iter=200)`` under the positivity rule, ``scipy.sparse.linalg.lsqr(atol=btol=1e-6)`` otherwise — called on a
+    ``LinearOperator`` whose products run on the device, so tolerances and stopping rules are SciPy's, not a restatement.
+    ``x_init`` is accepted and ignored, like the reference (it solves the base system afresh).  The reference pairs every new
+    geometry's matrix with the FIRST geometry's right-hand side and so fails in SciPy's shape check as soon as a perturbed
+    geometry gains or loses a ray; the same condition raises ``ValueError`` here."""
+    from scipy.optimize import lsq_linear
+    from scipy.sparse.linalg import LinearOperator, lsqr
+
+    img = np.asarray(projection_image)
+    d2, l2 = int(reconstruct_diameter_2d_pixel), int(reconstruct_length_2d_pixel)
+    d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
+    t = np.array([tilt_0, psi_0, dy_0], dtype=np.float64)
+    deltas = np.array([delta_tilt, delta_psi, delta_dy], dtype=np.float64)
+    lo = np.array([bounds_tilt[0], bounds_psi[0], bounds_dy[0]], dtype=np.float64)
+    hi = np.array([bounds_tilt[1], bounds_psi[1], bounds_dy[1]], dtype=np.float64)
+    target = min(2**26, int(max(d2 * l2, d3 * d3 * l3) * sym_oversample))   # solver:636-643, 663-665: the BOX's voxels here
+    pitch_pixel = round(rise_pixel * 360 / abs(twist_degree))
+    positive = positive_constraint > 0 or (positive_constraint < 0 and pitch_pixel > round(l3 * 2))
+
+    def problem(tt):
+        return PathAProblem(img, scale2d_to_3d=scale2d_to_3d, twist_degree=twist_degree, rise_pixel=rise_pixel, csym=csym,
+                            tilt_degree=float(tt[0]), psi_degree=float(tt[1]), dy_pixel=float(tt[2]),
+                            reconstruct_diameter_2d_pixel=d2, reconstruct_length_2d_pixel=l2, reconstruct_diameter_3d_pixel=d3,
+                            reconstruct_diameter_3d_inner_pixel=reconstruct_diameter_3d_inner_pixel,
+                            reconstruct_length_3d_pixel=l3, min_projection_lines=target, min_sym_pairs=target,
+                            interpolation=interpolation, device=device)
+
+    def solve(P, b_data):   # _solve_system (solver:697-716)
+        if P.m_data != len(b_data):
+            raise ValueError("Inconsistent shapes between `A` and `b`: the perturbed geometry has "
+                             f"{P.m_data} rays, the first one {len(b_data)} (the reference fails the same way)")
+        op = LinearOperator((P.m, P.n), matvec=P.matvec, rmatvec=P.rmatvec, dtype=np.float64)
+        b = np.concatenate((b_data.astype(np.float64), np.zeros(P.m_sym)))
+        if positive:
+            return lsq_linear(op, b, bounds=(0.0, float(np.max(b_data))), max_iter=200).x
+        return lsqr(op, b, atol=1e-6, btol=1e-6)[0]
+
+    with problem(t) as P0:
+        b_data = P0.b_data.copy()
+        x_cur = solve(P0, b_data)
+        p_0 = P0.matvec(x_cur)[: P0.m_data]
+    n_base = len(b_data)
+    b64 = b_data.astype(np.float64)
+    for _it in range(int(max_iter)):
+        J = np.zeros((n_base, 3), dtype=np.float64)
+        for i in range(3):
+            t_pert = t.copy()
+            t_pert[i] = np.clip(t_pert[i] + deltas[i], lo[i], hi[i])
+            actual = t_pert[i] - t[i]
+            if abs(actual) > 1e-12:
+                with problem(t_pert) as Pp:
+                    p_pert = Pp.matvec(x_cur)[: Pp.m_data]
+                nc = min(n_base, len(p_pert))
+                J[:nc, i] = (p_pert[:nc] - p_0[:nc]) / actual
+        r_0 = p_0 - b64
+        G = J.T @ J
+        g = J.T @ r_0
+        cond = np.linalg.cond(G) if np.linalg.det(G) != 0 else float("inf")
+        if cond > 1e10:
+            G = G + 1e-6 * np.diag(np.diag(G))
+        try:
+            delta_t = np.linalg.solve(G, -g)
+        except np.linalg.LinAlgError:
+            break
+        t_new = np.clip(t + delta_t, lo, hi)
+        step = t_new - t
+        t = t_new
+        if abs(step[0]) < tol_tilt and abs(step[1]) < tol_psi and abs(step[2]) < tol_dy:
+            break
+        with problem(t) as Pn:
+            x_cur = solve(Pn, b_data)
+            p_0 = Pn.matvec(x_cur)[: Pn.m_data]
+    return float(t[0]), float(t[1]), float(t[2]), x_cur, cosine_similarity(p_0, b64)
+
+
 def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, csym=1, tilt_degree=0, psi_degree=0,
                     dy_pixel=0, thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                     reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
@@ -685,11 +773,16 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     model = _model_of(algorithm)
     if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
         raise NotImplementedError("scores other than cosine need scikit-image")
-    if refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy"))):
-        raise NotImplementedError("tilt / psi / dy refinement is outside this slice")
+    refine = refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy")))
     img = np.asarray(projection_image)
     if _single and model is not None:
         raise NotImplementedError("the scikit-learn models run in the group solver")
+    if refine:
+        return _lsq_reconstruct_refined(img, scale2d_to_3d, twist_degree, rise_pixel, csym, tilt_degree, psi_degree, dy_pixel,
+                                        thresh_fraction, positive_constraint, reconstruct_diameter_3d_inner_pixel,
+                                        reconstruct_diameter_2d_pixel, reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel,
+                                        reconstruct_length_3d_pixel, sym_oversample, interpolation, fsc_test, algorithm,
+                                        refine_tilt_psi_dy_range, device)
     if interpolation == "nn" or not _single:   # the device-resident solver (a batch of one, or of three with half sets)
         return lsq_reconstruct_batch(img, scale2d_to_3d, [(twist_degree, rise_pixel, csym)], tilt_degree, psi_degree, dy_pixel,
                                      thresh_fraction, positive_constraint, reconstruct_diameter_3d_inner_pixel,
@@ -737,3 +830,46 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
         return (maps[0], maps[1], maps[2]), score
     rec3d = maps[0]
     return (rec3d, None, None), score
+
+
+
+def _lsq_reconstruct_refined(img, scale2d_to_3d, twist_degree, rise_pixel, csym, tilt_degree, psi_degree, dy_pixel, thresh_fraction,
+                             positive_constraint, d3_inner, d2, d3, l2, l3, sym_oversample, interpolation, fsc_test, algorithm,
+                             r_range, device):
+    """lsq_reconstruct with ``refine_tilt_psi_dy_range`` (solver:384-439): the ordinary solve, then the refinement started
+    from tilt = psi = dy = 0 (as the reference starts it, whatever the task's own angles), whose map and score replace the
+    solve's whenever they exist (the solve's own score is ``None`` at that point for every model, solver:330-342 with
+    ``train_fraction = 1``).  With half sets the three scores are recomputed from the ORIGINAL geometry's rows (solver:484-524):
+    ``A_data x_refined`` for the full set.  The refined parameters are kept in ``lsq_reconstruct._refined_params`` for the
+    caller's projections (pipeline.py:419-428 reads and clears them)."""
+    d2 = int(d2) if d2 > 0 else img.shape[0]
+    l2 = int(l2) if l2 > 0 else img.shape[1]
+    (rec, h1, h2), _score = lsq_reconstruct_batch(img, scale2d_to_3d, [(twist_degree, rise_pixel, csym)], tilt_degree, psi_degree, dy_pixel,
+                                                 thresh_fraction, positive_constraint, d3_inner, d2, d3, l2, l3, sym_oversample, fsc_test,
+                                                 interpolation=interpolation, device=device, algorithm=algorithm)[0]
+    tilt, psi, dy, x, score_refined = refine_tilt_psi_dy(
+        img, scale2d_to_3d, twist_degree, rise_pixel, csym, d2, l2, d3, d3_inner, l3, sym_oversample, interpolation, None,
+        delta_tilt=r_range.get("delta_tilt", 0.5), delta_psi=r_range.get("delta_psi", 1.0), delta_dy=r_range.get("delta_dy", 0.2),
+        max_iter=r_range.get("max_iter", 5), bounds_tilt=(-r_range.get("tilt", 30.0), r_range.get("tilt", 30.0)),
+        bounds_psi=(-r_range.get("psi", 45.0), r_range.get("psi", 45.0)), bounds_dy=(-r_range.get("dy", 5.0), r_range.get("dy", 5.0)),
+        positive_constraint=positive_constraint, algorithm=algorithm, device=device)
+    lsq_reconstruct._refined_params = {"tilt": tilt, "psi": psi, "dy": dy}
+    mask = get_cylindrical_mask(int(l3), int(d3), int(d3), rmin=d3_inner / 2, rmax=int(d3) // 2 - 1)
+    rec = np.zeros(mask.shape, dtype=np.float32)
+    rec[mask] = x.astype(np.float32)
+    if not (fsc_test and fsc_test >= 1):
+        return (rec, None, None), score_refined
+    # half sets: every score again from the rows of the task's own geometry
+    scores = []
+    target = min(2**26, int(max(d2 * l2, int(np.count_nonzero(mask))) * sym_oversample))
+    for half, vol in ((0, rec), (1, h1), (2, h2)):
+        with PathAProblem(img, scale2d_to_3d=scale2d_to_3d, twist_degree=twist_degree, rise_pixel=rise_pixel, csym=csym,
+                          tilt_degree=tilt_degree, psi_degree=psi_degree, dy_pixel=dy_pixel, reconstruct_diameter_2d_pixel=d2,
+                          reconstruct_length_2d_pixel=l2, reconstruct_diameter_3d_pixel=int(d3), reconstruct_diameter_3d_inner_pixel=d3_inner,
+                          reconstruct_length_3d_pixel=int(l3), min_projection_lines=target, min_sym_pairs=target, interpolation=interpolation,
+                          fsc_mode=int(fsc_test) if half else 0, fsc_half=half, device=device) as P:
+            pred = P.matvec(vol[mask].astype(np.float64))[: P.m_data]
+            if thresh_fraction >= 0:
+                pred = np.clip(pred, 0, None)
+            scores.append(cosine_similarity(pred, P.b_data.astype(np.float64)))
+    return (rec, h1, h2), scores[0] / 2 + (scores[1] + scores[2]) / 4

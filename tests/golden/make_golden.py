@@ -447,6 +447,53 @@ def g8_rotate_shift():
     print("g8_rotate_shift", len(cases))
 
 
+def g16_refine_tilt_psi_dy():
+    """refine_tilt_psi_dy (solver_linear_regression.py:550-841) on a 32 x 32 helix simulated with a tilt, an in-plane
+    rotation and a shift: the refined parameters, the map and the score, for both projectors and both branches of its
+    solver (positive: lsq_linear; unbounded: lsqr); and lsq_reconstruct with refine_tilt_psi_dy_range (solver:384-439) end to
+    end.  The box (D2d = D3d = 20) keeps the number of rays the same under the perturbations — the function's own b is the
+    first geometry's, so it raises as soon as a perturbed geometry gains or loses a ray."""
+    from helicon.webApps.denovo3D import solver_linear_regression as S
+
+    arrs = {}
+    n, apix = 32, 5.0
+    d, br = 0.4 * n * apix, 2 * apix
+    kw = dict(scale2d_to_3d=1.0, twist_degree=29.0, rise_pixel=2.0, csym=1, reconstruct_diameter_2d_pixel=20,
+              reconstruct_length_2d_pixel=32, reconstruct_diameter_3d_pixel=20, reconstruct_diameter_3d_inner_pixel=0,
+              reconstruct_length_3d_pixel=6, sym_oversample=1)
+    cases = [("nn", 1, (2.0, 1.5, 1.0)), ("nn", 0, (2.0, 1.5, 1.0)), ("linear", 1, (2.0, 1.5, 1.0)), ("nn", 1, (0.0, 6.0, -2.0))]
+    for k, (interp, pos, (tilt, psi, dy)) in enumerate(cases):
+        clean = utils.simulate_helical_projection(1, 29.0, 10.0, 1, d, br, 0, 0, n, n, apix, tilt=tilt, psi=psi, dy=dy * apix)
+        himg = (clean / clean.max()).astype(np.float32)
+        arrs[f"case{k}_image"] = himg
+        arrs[f"case{k}_args"] = np.asarray([{"nn": 0, "linear": 1}[interp], pos, tilt, psi, dy], dtype=np.float64)
+        try:
+            t0, t1, t2, x, score = S.refine_tilt_psi_dy(projection_image=himg, interpolation=interp, x_init=None, positive_constraint=pos,
+                                                        bounds_tilt=(-5.0, 5.0), bounds_psi=(-8.0, 8.0), bounds_dy=(-3.0, 3.0), verbose=0, cpu=1, **kw)
+        except ValueError as e:   # (its b is the first geometry's: a geometry with another number of rays fails SciPy's shape check)
+            arrs[f"case{k}_raised"] = np.asarray([1])
+            print("g16 case", k, interp, pos, "raised", str(e)[:80], flush=True)
+            continue
+        arrs[f"case{k}_t"] = np.asarray([t0, t1, t2], dtype=np.float64)
+        arrs[f"case{k}_x"] = np.asarray(x, dtype=np.float64)
+        arrs[f"case{k}_score"] = np.asarray([score], dtype=np.float64)
+        print("g16 case", k, interp, pos, [round(float(v), 5) for v in (t0, t1, t2)], round(float(score), 6), flush=True)
+    # end to end: lsq_reconstruct with the refinement switched on (fsc_test 0: the score is the refinement's); unbounded, the
+    # branch that went through above
+    himg = arrs["case1_image"]
+    if hasattr(S.lsq_reconstruct, "_refined_params"):
+        S.lsq_reconstruct._refined_params = {}
+    (rec, _, _), score = S.lsq_reconstruct(projection_image=himg, positive_constraint=0, interpolation="nn", algorithm=dict(model="lsq"), cpu=1,
+                                           refine_tilt_psi_dy_range=dict(tilt=5.0, psi=8.0, dy=3.0), **{k_: v for k_, v in kw.items() if k_ != "reconstruct_diameter_3d_inner_pixel"})
+    rp = getattr(S.lsq_reconstruct, "_refined_params", {})
+    arrs["e2e_rec3d"] = rec
+    arrs["e2e_score"] = np.asarray([score], dtype=np.float64)
+    arrs["e2e_refined"] = np.asarray([rp.get("tilt", np.nan), rp.get("psi", np.nan), rp.get("dy", np.nan)], dtype=np.float64)
+    arrs["kw"] = np.asarray([1.0, 29.0, 2.0, 1, 20, 32, 20, 0, 6, 1], dtype=np.float64)
+    print("g16 e2e", round(float(score), 6), arrs["e2e_refined"], flush=True)
+    np.savez_compressed(OUT / "g16_refine_tilt_psi_dy.npz", **arrs)
+
+
 def g15_rotate_shift_cubic():
     """helicon.rotate_shift_image(order=3) (lib/transforms.py:315-369: scipy affine_transform, cubic spline, constant) — what
     auto_horizontalize's last step calls (webApps/denovo3D/utils.py:420-423) —, helicon.pad_to_size (lib/transforms.py:441-479)
@@ -646,7 +693,7 @@ def g14_sklearn_models():
 if __name__ == "__main__":
     assert "reference" in os.path.abspath(helicon.__file__), helicon.__file__
     makers = [g1_simulate, g2_scores, g3_composed, g3b_general_sizes, g3c_general_sizes_tilted, g4_path_a, g4b_path_a_linear, g5_lsq, g6_filters,
-              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random, g15_rotate_shift_cubic,
+              g7_helical_sym, g8_rotate_shift, g9_process_one_task, g10_transform_map, g11_fsc_halves, g12_polymer, g13_fsc_random, g15_rotate_shift_cubic, g16_refine_tilt_psi_dy,
               g14_sklearn_models]
     only = set(sys.argv[1:])   # e.g. "g8_rotate_shift": regenerate just that fixture
     for make in makers:

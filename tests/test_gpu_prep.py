@@ -62,6 +62,8 @@ def test_transform_image_against_the_oracle(dtype):
         H.denovo3D.transform_image(flat, order=3)
     with pytest.raises(NotImplementedError):
         H.denovo3D.transform_image(flat, mode="edge")
+    with pytest.raises(TypeError):
+        H.denovo3D.transform_image(np.ones((8, 8), dtype=np.uint8), rotation=3.0)   # (skimage would rescale it to [0, 1])
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
