@@ -50,5 +50,7 @@ else
   rm -rf $O/sqlin/sq1 $O/sqlin/sq2 $O/sqlin/sq3
   $T 300 python3 tools/path_a_groups.py 512 --linear > $O/path_a_groups_linear.txt 2>&1
   tail -2 $O/path_a_groups_linear.txt
+  $T 300 python3 tools/prep_bench.py 512 > $O/image_prep.json 2> $O/image_prep.err
+  tail -2 $O/image_prep.json | cut -c1-400
   echo collected C
 fi
