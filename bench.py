@@ -509,8 +509,9 @@ def config_legs(args, torch, dev):
         ("C4_1024", 1024, 1, sweep_axis(0.01, 5.00, 0.01), sweep_axis(4.000, 6.495, 0.005), 2, {}),
         ("C5_64_segments", 512, 64, sweep_axis(0.02, 4.00, 0.02), sweep_axis(4.25, 5.24, 0.01), 5, {}),
         ("general_400", (400, 400), 1, tw5[70:170], rs5, 3, dict(apix=5.0, truth=(6.0, 23.75))),
-        # (a 200-pixel box holds 42 subunits: at noise 0.5 std a neighbour of the truth leads; 0.25 std is identifiable)
-        ("general_200", (200, 200), 1, tw5[20:220], rs5, 3, dict(apix=5.0, truth=(6.0, 23.75), noise=0.25)),
+        # (a 200-pixel box holds 42 subunits and the rise grid's step is a thousandth of the rise: at noise 0.5 and 0.25 std the
+        # next rise leads by 1e-5 in the CPU oracle too; 0.1 std separates them by 3e-4)
+        ("general_200", (200, 200), 1, tw5[20:220], rs5, 3, dict(apix=5.0, truth=(6.0, 23.75), noise=0.1)),
         ("general_400_64_segments", (400, 400), 64, tw5[70:170], rs5, 3, dict(apix=5.0, truth=(6.0, 23.75))),
     )
     for name, shape, segments, tws, rss, reps, kw in legs:
