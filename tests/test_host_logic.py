@@ -96,7 +96,7 @@ def test_no_cxx_exception_crosses_the_c_abi():
     # and the source agrees: no entry point with a body of its own is left outside a try block
     import re
     csrc = ROOT / "helicon_amd" / "csrc"
-    for f in ("helicon_hip.hip", "fourier_zoom.inc", "path_a_batch.inc", "path_a_host.inc"):
+    for f in ("helicon_hip.hip", "fourier_zoom.inc", "path_a_batch.inc", "path_a_host.inc", "image_prep.inc"):
         text_ = (csrc / f).read_text()
         for m in re.finditer(r'^(?:extern "C" )?(?:int|int64_t|void) (hh_\w+)\([^;{]*\)\s*(try)?\s*\{(.*)$', text_, re.M):
             one_liner = m.group(3).rstrip().endswith("}")
@@ -122,6 +122,41 @@ def test_no_gpu_means_loud_failure():
         H.SweepEngine((48, 96))            # a general size: valid, but there is still no CPU path
     with pytest.raises(ValueError):
         H.SweepEngine(4)
+
+
+def test_image_preparation_entry_points_check_their_arguments_and_have_no_cpu_path():
+    """The four entry points of csrc/image_prep.inc: bad arguments are refused before anything touches a device (HH_ERR_ARG,
+    a message), and without a GPU a valid call is a loud error — there is no CPU fallback; the Python mirrors refuse what they
+    do not provide."""
+    import ctypes as C
+    import torch
+    from helicon_amd import denovo3D as D
+
+    L = _lib.lib()
+    img = np.ones((8, 8), dtype=np.float32)
+    out = np.empty_like(img)
+    eye = (C.c_double * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    m8 = (C.c_double * 8)()
+    assert L.hh_warp_affine_2d(0, img.ctypes.data, 0, 8, 8, eye, 3, 0.0, 1, out.ctypes.data) == -1          # order 3: not provided
+    assert b"hh_warp_affine_2d" in L.hh_last_error(None)
+    assert L.hh_warp_affine_2d(0, None, 0, 8, 8, eye, 1, 0.0, 1, out.ctypes.data) == -1
+    assert L.hh_rescale_2d(0, img.ctypes.data, 0, 8, 8, 0, 4, 3, 1, 1, out.ctypes.data) == -1              # empty output
+    assert L.hh_rescale_2d(0, img.ctypes.data, 0, 8, 8, 4, 4, 2, 1, 1, out.ctypes.data) == -1              # order 2
+    assert L.hh_helix_moments(0, img.ctypes.data, 0, 0, 8, 0.0, m8) == -1
+    assert L.hh_affine_transform_2d_cubic(0, None, 8, 8, (C.c_double * 4)(1, 0, 0, 1), (C.c_double * 2)(), None) == -1
+    with pytest.raises(NotImplementedError):
+        D.transform_image(img, order=3)
+    with pytest.raises(NotImplementedError):
+        D.rescale(img, 0.5, order=2)
+    with pytest.raises(TypeError):
+        D.down_scale(np.ones((8, 8), dtype=np.int16), 2.0, 1.0)
+    assert D.down_scale(img, 1.0, 1.0) is img                                                               # nothing to do: no device needed
+    np.testing.assert_array_equal(D.pad_to_size(img, (10, 9)).shape, (10, 9))
+    if not torch.cuda.is_available():
+        for call in (lambda: D.transform_image(img, rotation=5.0), lambda: D.rescale(img, 0.5), lambda: D.estimate_helix_rotation_center_diameter(img),
+                     lambda: D.rotate_shift_image(img, 5.0, order=3)):
+            with pytest.raises(H.HeliconHipError, match="no such HIP device"):
+                call()
 
 
 def test_product_never_imports_oracle():
