@@ -232,6 +232,9 @@ __device__ __forceinline__ void gr_dft(float2 (&a)[R]) {
 #ifndef GR_ABLATE
 #define GR_ABLATE 0   // timing-only builds (tools/variants): 1 no build, 2 no step 1, 4 no step 2, 8 no moments, 16 no reduction
 #endif
+#ifndef GR_DUAL
+#define GR_DUAL 0     // 1: two rows per lane slot where step 1 leaves half of a slot's lanes idle (GrShape::DUAL) — correct (all 109 sizes against the oracle) and slower where it matters: 200 x 200 16.4 -> 14.7 M candidates/s, 96 x 128 46.9 -> 40.9 M, 250 x 250 9.66 -> 10.04 M (two workgroups per compute unit instead of three)
+#endif
 constexpr int GR_WAVES = 4;
 constexpr int GR_THREADS = 64 * GR_WAVES;
 constexpr int GR_KG_PF = 16;     // rows of column factors the register prefetch is sized for (more: k_gen_fused)
@@ -246,9 +249,17 @@ constexpr int gr_row_len(int r1, int r2) {
 
 template <int R1, int R2>
 struct GrShape {
-  static constexpr int L = R1 > R2 ? R1 : R2;       // lanes per row
-  static constexpr int RPW = 64 / L;                // rows per wavefront
-  static constexpr int RPB = RPW * GR_WAVES;        // rows per workgroup
+  static constexpr int L = R1 > R2 ? R1 : R2;       // lanes per row slot
+  static constexpr int RPW = 64 / L;                // row slots per wavefront
+  // Step 1 keeps only R2 of a slot's L lanes busy.  When two sets of R2 lanes fit a slot (2 R2 <= L), a wavefront carries TWO
+  // rows per slot: step 1 transforms both at once (lanes [0, R2) the first row's columns, [R2, 2 R2) the second's), step 2 and
+  // the moments run once per row on all R1 lanes (200 = 20 x 10: the 20-point transforms of step 1 ran on 30 of 64 lanes).
+  // (short rows only: above 256 points the second row's accumulators and weights do not fit the registers — 48 to 160 bytes
+  // of scratch at 28 x 14 and 32 x 16 when tried)
+  static constexpr bool DUAL = GR_DUAL && 2 * R2 <= L && R1 >= R2 && R1 * R2 <= 256;
+  static constexpr int PH = DUAL ? 2 : 1;           // rows per slot
+  static constexpr int RW = RPW * PH;               // rows per wavefront (row ph * RPW + slot)
+  static constexpr int RPB = RW * GR_WAVES;         // rows per workgroup
   static constexpr int S = R1 | 1;                  // odd stride of the transposed layout between the steps
   static constexpr int NX = R1 * R2;
   static constexpr int NXP = (NX + 3) / 4 * 4;
@@ -264,7 +275,7 @@ struct GrShape {
   static constexpr bool TW_REGS = NX > 256 && R1 + R2 <= 48;
   static constexpr bool TW_LDS = NX <= 256;
   static constexpr bool W_REGS = R1 + R2 <= 48;
-  static constexpr int MIN_BLOCKS = NX > 256 ? 2 : 3;
+  static constexpr int MIN_BLOCKS = (NX > 256 || DUAL) ? 2 : 3;   // (DUAL: twice the rows in LDS, two workgroups per compute unit at most)
   static_assert(RPW >= 1 && L <= 64, "radix too large");
 };
 
@@ -287,10 +298,8 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
   const int m_raw = lane / C::L, j = lane - m_raw * C::L;
   const bool lane_ok = m_raw < C::RPW;
   const int m = lane_ok ? m_raw : C::RPW - 1;
-  const int rib = wave * C::RPW + m;                 // the lane's row inside the workgroup
-  const int row = blockIdx.x * C::RPB + rib;
-  const bool row_ok = lane_ok && row < a.nky;
-  float2* const myrow = rowsb + (size_t)rib * C::ROWLEN;
+  // the lane's rows inside the workgroup: slot m holds row ph * RPW + m of the wavefront for ph < PH
+  const int rib0 = wave * C::RW + m;
   const int run = a.layer_run[blockIdx.y];
   const int cfirst = a.layer_first[blockIdx.y], nc = a.layer_count[blockIdx.y];
   const int n_e4 = a.kg * C::NG;
@@ -306,7 +315,9 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
     }
   }
   // step-1 twiddles W_nx^(j k1) and the weights of the bins kx = j + R1 k2 this lane will hold after step 2
-  const int j1 = min(j, R2 - 1), j2 = min(j, R1 - 1);
+  // step 1: (DUAL) lanes [R2, 2 R2) of a slot work on the slot's second row
+  const int ph1 = C::DUAL && j >= R2 ? 1 : 0;
+  const int j1 = min(j - ph1 * R2, R2 - 1), j2 = min(j, R1 - 1);
   float2 tw1[C::TW_REGS ? R1 : 1];
   if constexpr (C::TW_REGS) {
 #pragma unroll
@@ -317,12 +328,18 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
       twl[e] = a.tw_nx[jj * k1];
     }
   }
-  const bool w_ok = row_ok && j < R1;
-  const float2* const wrow = a.w2 + (size_t)(w_ok ? row : 0) * C::NX + j2;
-  float2 wreg[C::W_REGS ? R2 : 1];
-  if constexpr (C::W_REGS) {
+  bool w_ok[C::PH];
+  const float2* wrow[C::PH];
+  float2 wreg[C::PH][C::W_REGS ? R2 : 1];
 #pragma unroll
-    for (int k2 = 0; k2 < R2; ++k2) wreg[k2] = w_ok ? wrow[R1 * k2] : make_float2(0.f, 0.f);
+  for (int ph = 0; ph < C::PH; ++ph) {
+    const int row = blockIdx.x * C::RPB + rib0 + ph * C::RPW;
+    w_ok[ph] = lane_ok && row < a.nky && j < R1;
+    wrow[ph] = a.w2 + (size_t)(w_ok[ph] ? row : 0) * C::NX + j2;
+    if constexpr (C::W_REGS) {
+#pragma unroll
+      for (int k2 = 0; k2 < R2; ++k2) wreg[ph][k2] = w_ok[ph] ? wrow[ph][R1 * k2] : make_float2(0.f, 0.f);
+    }
   }
 
   // column factors of the first candidate
@@ -364,25 +381,25 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
     // the groups of the last, partial pass out as (row, group) items takes fewer item passes than there are rows per
     // wavefront (36 left-over groups x 3 rows at nx = 400: two item passes of 8 FMAs per table row instead of one
     // grouped pass of 24 with 28 lanes idle), they are.
-    constexpr int REM0 = C::NG % 64, IPASS = (REM0 * C::RPW + 63) / 64;
-    constexpr bool FLAT = REM0 > 0 && IPASS < C::RPW;
-    constexpr int FULL = FLAT ? C::NG / 64 : (C::NG + 63) / 64, REM = FLAT ? REM0 : 0, ITEMS = REM * C::RPW;
+    constexpr int REM0 = C::NG % 64, IPASS = (REM0 * C::RW + 63) / 64;
+    constexpr bool FLAT = REM0 > 0 && IPASS < C::RW;
+    constexpr int FULL = FLAT ? C::NG / 64 : (C::NG + 63) / 64, REM = FLAT ? REM0 : 0, ITEMS = REM * C::RW;
     if (!(GR_ABLATE & 1)) {
 #pragma unroll
       for (int f = 0; f < FULL; ++f) {
         const int xg = lane + 64 * f;
         if (xg >= C::NG) break;   // (the partial pass, when it is kept grouped)
-        const float2* const g0 = gs + (size_t)(wave * C::RPW) * a.rows_lds + cg[xg];
+        const float2* const g0 = gs + (size_t)(wave * C::RW) * a.rows_lds + cg[xg];
         const float* const erow = eg + 4 * xg;
-        float2 p[C::RPW][4];
+        float2 p[C::RW][4];
 #pragma unroll
-        for (int r = 0; r < C::RPW; ++r)
+        for (int r = 0; r < C::RW; ++r)
 #pragma unroll
           for (int q = 0; q < 4; ++q) p[r][q] = make_float2(0.f, 0.f);
         for (int k = 0; k < kc; ++k) {
           const float4 e4 = *reinterpret_cast<const float4*>(erow + (size_t)k * C::NXP);
 #pragma unroll
-          for (int r = 0; r < C::RPW; ++r) {
+          for (int r = 0; r < C::RW; ++r) {
             const float2 gk = g0[(size_t)r * a.rows_lds + k];
             p[r][0].x = fmaf(e4.x, gk.x, p[r][0].x); p[r][0].y = fmaf(e4.x, gk.y, p[r][0].y);
             p[r][1].x = fmaf(e4.y, gk.x, p[r][1].x); p[r][1].y = fmaf(e4.y, gk.y, p[r][1].y);
@@ -391,8 +408,8 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
           }
         }
 #pragma unroll
-        for (int r = 0; r < C::RPW; ++r) {
-          float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
+        for (int r = 0; r < C::RW; ++r) {
+          float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RW + r) * C::ROWLEN + 4 * xg);
           dst[0] = make_float4(p[r][0].x, p[r][0].y, p[r][1].x, p[r][1].y);
           dst[1] = make_float4(p[r][2].x, p[r][2].y, p[r][3].x, p[r][3].y);
         }
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
           const int it = lane + 64 * u;
           if (it < ITEMS) {
             const int r = it / REM, xg = 64 * FULL + (it - r * REM);
-            const float2* const g0 = gs + (size_t)(wave * C::RPW + r) * a.rows_lds + cg[xg];
+            const float2* const g0 = gs + (size_t)(wave * C::RW + r) * a.rows_lds + cg[xg];
             const float* const erow = eg + 4 * xg;
             float2 p0 = make_float2(0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
             for (int k = 0; k < kc; ++k) {
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
               p2.x = fmaf(e4.z, gk.x, p2.x); p2.y = fmaf(e4.z, gk.y, p2.y);
               p3.x = fmaf(e4.w, gk.x, p3.x); p3.y = fmaf(e4.w, gk.y, p3.y);
             }
-            float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RPW + r) * C::ROWLEN + 4 * xg);
+            float4* const dst = reinterpret_cast<float4*>(rowsb + (size_t)(wave * C::RW + r) * C::ROWLEN + 4 * xg);
             dst[0] = make_float4(p0.x, p0.y, p1.x, p1.y);
             dst[1] = make_float4(p2.x, p2.y, p3.x, p3.y);
           }
@@ -424,70 +441,78 @@ __global__ __launch_bounds__(GR_THREADS, (GrShape<R1, R2>::MIN_BLOCKS)) void k_g
     gr_wave_fence();
     // ---- step 1: R1 points x = j + R2 r per lane
     {
+      float2* const myrow = rowsb + (size_t)(rib0 + ph1 * C::RPW) * C::ROWLEN;
       float2 v[R1];
 #pragma unroll
       for (int r = 0; r < R1; ++r) v[r] = myrow[j1 + R2 * r];
       if (!(GR_ABLATE & 2)) gr_dft<R1>(v);
       gr_wave_fence();   // (program order: every lane's reads above precede the writes below)
-      if (lane_ok && j < R2) {
-        myrow[j * C::S] = v[0];
+      if (lane_ok && j < C::PH * R2) {
+        myrow[j1 * C::S] = v[0];
 #pragma unroll
         for (int k1 = 1; k1 < R1; ++k1) {
           float2 t;
           if constexpr (C::TW_REGS) t = tw1[k1];
           else if constexpr (C::TW_LDS) t = twl[k1 * R2 + j1];
           else t = a.tw_nx[j1 * k1];
-          myrow[j * C::S + k1] = gr_mul(v[k1], t);
+          myrow[j1 * C::S + k1] = gr_mul(v[k1], t);
         }
       }
     }
     gr_wave_fence();
-    // ---- step 2: A[.][k1 = j] -> the bins kx = j + R1 k2, and the row's three masked moments
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    {
-      float2 v[R2];
+    // ---- step 2 (once per row of the slot): A[.][k1 = j] -> the bins kx = j + R1 k2, and the row's three masked moments
 #pragma unroll
-      for (int r = 0; r < R2; ++r) v[r] = myrow[r * C::S + j2];
-      if (!(GR_ABLATE & 4)) gr_dft<R2>(v);
+    for (int ph = 0; ph < C::PH; ++ph) {
+      const int rib = rib0 + ph * C::RPW;
+      const int row = blockIdx.x * C::RPB + rib;
+      const bool row_ok = lane_ok && row < a.nky;
+      const float2* const myrow = rowsb + (size_t)rib * C::ROWLEN;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      {
+        float2 v[R2];
 #pragma unroll
-      for (int k2 = 0; k2 < R2; ++k2) {
-        const float av = (GR_ABLATE & 8) ? v[k2].x + v[k2].y : __builtin_amdgcn_sqrtf(v[k2].x * v[k2].x + v[k2].y * v[k2].y);
-        const float q = (GR_ABLATE & 8) ? av : a.log_flag ? __log2f(1.0f + av) : av;
-        float2 w;
-        if constexpr (C::W_REGS) w = wreg[k2];
-        else w = w_ok ? wrow[R1 * k2] : make_float2(0.f, 0.f);
-        // several segments: the masked q goes to HBM for the contraction with every segment's centred spectrum
-        // (k_segment_corr); bins outside the mask carry no weight in any segment
-        if (a.q_out && w_ok) a.q_out[(size_t)(cfirst + cc) * a.q_stride + (size_t)row * C::NX + j + R1 * k2] = w.x > 0.f ? q : 0.f;
-        s1 = fmaf(w.x, q, s1);
-        s2 = fmaf(w.x * q, q, s2);
-        s3 = fmaf(w.y, q, s3);
+        for (int r = 0; r < R2; ++r) v[r] = myrow[r * C::S + j2];
+        if (!(GR_ABLATE & 4)) gr_dft<R2>(v);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+          const float av = (GR_ABLATE & 8) ? v[k2].x + v[k2].y : __builtin_amdgcn_sqrtf(v[k2].x * v[k2].x + v[k2].y * v[k2].y);
+          const float q = (GR_ABLATE & 8) ? av : a.log_flag ? __log2f(1.0f + av) : av;
+          float2 w;
+          if constexpr (C::W_REGS) w = wreg[ph][k2];
+          else w = w_ok[ph] ? wrow[ph][R1 * k2] : make_float2(0.f, 0.f);
+          // several segments: the masked q goes to HBM for the contraction with every segment's centred spectrum
+          // (k_segment_corr); bins outside the mask carry no weight in any segment
+          if (a.q_out && w_ok[ph]) a.q_out[(size_t)(cfirst + cc) * a.q_stride + (size_t)row * C::NX + j + R1 * k2] = w.x > 0.f ? q : 0.f;
+          s1 = fmaf(w.x, q, s1);
+          s2 = fmaf(w.x * q, q, s2);
+          s3 = fmaf(w.y, q, s3);
+        }
       }
-    }
-    // sum over the row's L lanes (segments of the wavefront): lane j = 0 of each row ends with the total.  When L is a
-    // multiple of 4 the rows start on quad boundaries: the first two levels are DPP quad permutes (no LDS queue, no
-    // masks: every lane of a quad ends with the quad's sum), the rest shuffles across quads.
-    constexpr int RED0 = (C::L % 4 == 0) ? 4 : 1;
-    if constexpr (RED0 == 4) {
+      // sum over the row's L lanes (segments of the wavefront): lane j = 0 of each row ends with the total.  When L is a
+      // multiple of 4 the rows start on quad boundaries: the first two levels are DPP quad permutes (no LDS queue, no
+      // masks: every lane of a quad ends with the quad's sum), the rest shuffles across quads.
+      constexpr int RED0 = (C::L % 4 == 0) ? 4 : 1;
+      if constexpr (RED0 == 4) {
 #define GR_QUAD_ADD(V, CTRL) V += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, 0xF, 0xF, false))
-      GR_QUAD_ADD(s1, 0xB1); GR_QUAD_ADD(s2, 0xB1); GR_QUAD_ADD(s3, 0xB1);   // quad_perm [1,0,3,2]
-      GR_QUAD_ADD(s1, 0x4E); GR_QUAD_ADD(s2, 0x4E); GR_QUAD_ADD(s3, 0x4E);   // quad_perm [2,3,0,1]
+        GR_QUAD_ADD(s1, 0xB1); GR_QUAD_ADD(s2, 0xB1); GR_QUAD_ADD(s3, 0xB1);   // quad_perm [1,0,3,2]
+        GR_QUAD_ADD(s1, 0x4E); GR_QUAD_ADD(s2, 0x4E); GR_QUAD_ADD(s3, 0x4E);   // quad_perm [2,3,0,1]
 #undef GR_QUAD_ADD
-    }
-#pragma unroll
-    for (int off = RED0; off < ((GR_ABLATE & 16) ? 1 : C::L); off <<= 1) {
-      const float t1 = __shfl_down(s1, off, 64), t2 = __shfl_down(s2, off, 64), t3 = __shfl_down(s3, off, 64);
-      if (j + off < C::L) {
-        s1 += t1;
-        s2 += t2;
-        s3 += t3;
       }
-    }
-    if (row_ok && j == 0) {
-      double* const o = a.partials + ((size_t)(cfirst + cc) * a.nky + row) * 3;
-      o[0] = s1;
-      o[1] = s2;
-      o[2] = s3;
+#pragma unroll
+      for (int off = RED0; off < ((GR_ABLATE & 16) ? 1 : C::L); off <<= 1) {
+        const float t1 = __shfl_down(s1, off, 64), t2 = __shfl_down(s2, off, 64), t3 = __shfl_down(s3, off, 64);
+        if (j + off < C::L) {
+          s1 += t1;
+          s2 += t2;
+          s3 += t3;
+        }
+      }
+      if (row_ok && j == 0) {
+        double* const o = a.partials + ((size_t)(cfirst + cc) * a.nky + row) * 3;
+        o[0] = s1;
+        o[1] = s2;
+        o[2] = s3;
+      }
     }
     if (a.halves == 1) __syncthreads();   // one buffer: every wavefront has finished with this candidate's factors
     if (cc + 1 < nc) GR_PARK(a.halves == 2 ? (half ^ 1) : 0);
@@ -579,7 +604,9 @@ bool gen_rows_plan(int nx, int rows_lds, int kg, GenRowsPlan* plan) {
     if (e.r1 * e.r2 != nx) return;
     // vector instructions per row, roughly: both transforms ~ R (1 + log2 R) per lane, one wavefront pass serves RPW rows
     auto work = [](int r) { double l = 0; for (int t = r; t > 1; t >>= 1) l += 1; return r * (l + 1.0); };
-    const double cost = (work(e.r1) + work(e.r2)) / (double)(e.rpb / GR_WAVES);
+    // (two rows per lane slot, GrShape::DUAL: step 1 serves all the wavefront's rows at once, step 2 runs once per row of a slot)
+    const int slots = 64 / std::max(e.r1, e.r2), rw = e.rpb / GR_WAVES, ph = rw / slots;
+    const double cost = (work(e.r1) + ph * work(e.r2)) / (double)rw;
     if (cost < best_cost) { best_cost = cost; best = &e; }
   });
   if (!best) return false;
