@@ -53,7 +53,8 @@
 #define HH_ABLATE 0        // timing-only builds: 1 no raster, 2 no K_A FFT, 4 no K_A store, 8 no twiddle loads,
                            // 16 no K_B FFT, 32 no K_B epilogue math, 64 no K_B weight loads; run-table first pass:
                            // 128 no stores, 256 no accumulation, 1024 no table staging; fused pass: 2048 no panel
-                           // accumulation, 4096 no column-factor prefetch (16 / 32 as for K_B), 8192 no second exchange
+                           // accumulation, 4096 no column-factor prefetch (16 / 32 as for K_B), 8192 no second exchange,
+                           // 65536 compact q stores of every candidate into 64 rows (no HBM write stream)
 #endif
 #ifndef HH_KA_WPS
 #define HH_KA_WPS 8        // K_A: waves per SIMD the register allocator must leave room for (4 workgroups per CU)
@@ -1774,7 +1775,7 @@ __global__ __launch_bounds__(N, (N >= 256 ? HH_KF_WPS : 1)) void k_fused_pass(Fu
   // candidate b's eight q of this lane -> its compact row
   auto store_q_compact = [&](size_t b, const float (&qv)[8]) {
     if constexpr (T <= 64) {
-      float* const qb = a.q_out + b * a.q_stride;
+      float* const qb = a.q_out + ((HH_ABLATE & 65536) ? (b & 63) : b) * a.q_stride;   // (65536: timing only — every candidate's q into 64 cache-resident rows)
       int base = qrow_base;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
