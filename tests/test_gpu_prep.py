@@ -162,3 +162,37 @@ def test_process_one_task_prepares_the_image_like_the_reference_pipeline():
         bad = list(_task_args(img, 29.0, 25.0))
         bad[16] = "wavelet"
         H.process_one_task(*bad)
+
+
+def test_the_least_squares_task_on_a_down_scaled_image_is_the_manual_composition():
+    """process_one_task with the reference's own scorer and target_apix2d > apix2d_orig (pipeline.py:268-275 rescales, 305-349
+    sizes the box on the rescaled grid from lengths worked out on the original one, 398-432 puts the map back on the ORIGINAL
+    grid): score and map equal lsq_reconstruct called by hand on the oracle's down-scaled image with lsq_box's numbers, the
+    projections have the original image's size, the metadata carries both pixel sizes."""
+    from helicon_amd.solver import lsq_reconstruct
+
+    apix0, a2 = 2.5, 5.0
+    n0y, n0x = 64, 96
+    d, br = 0.4 * n0y * apix0, 2 * apix0
+    img = O.simulate_helical_projection(1, 29.0, 10.0, 1, d, br, 0, 0, n0y, n0x, apix0).astype(np.float32)
+    img = img / img.max()
+    twist, rise = 29.0, 10.0
+    task = (0, 1, img.copy(), "mem", 1, twist, rise, (rise, rise), 1, 0.0, (0, 0), 0.0, 0, 0.0, 0, apix0, "", 0, 0, 0, 5.0, a2, -1, -1,
+            -1, d, 0, -1, 1, "nn", 0, 1, "cosine", {"model": "lsq", "scorer": "lsq"}, 0, 1)
+    score, ret, meta = H.process_one_task(*task)
+    small = P.down_scale(img, a2, apix0)
+    ny, nx = small.shape
+    assert (ny, nx) == (32, 48) and meta[0].shape == (ny, nx)
+    np.testing.assert_allclose(meta[0], small, rtol=0, atol=3e-6)
+    assert meta[3] == 5.0 and meta[4] == a2                       # target_apix3d, target_apix2d
+    a3, d2, l2, d3, d3i, l3, so = D.lsq_box(ny, nx, a2, rise, (rise, rise), (0, 0), 5.0, -1, d, 0, -1, 1, True, orig=(n0y, n0x, apix0))
+    assert tuple(ret[4:8]) == (d2, d3, l2, l3)
+    (rec, _, _), want = lsq_reconstruct(small, a2 / a3, twist, rise / a3, 1, 0.0, 0.0, 0.0, thresh_fraction=-1, positive_constraint=-1,
+                                        reconstruct_diameter_3d_inner_pixel=d3i, reconstruct_diameter_2d_pixel=d2,
+                                        reconstruct_diameter_3d_pixel=d3, reconstruct_length_2d_pixel=l2, reconstruct_length_3d_pixel=l3,
+                                        sym_oversample=so, interpolation="nn")
+    assert score == pytest.approx(want, abs=1e-6)
+    np.testing.assert_allclose(ret[3][0], rec, rtol=0, atol=1e-5 * max(1e-9, float(np.abs(rec).max())))
+    # the symmetrised map goes back on the original grid: at least 1.2 pitches or the original length along the axis
+    pitch_px = int(360 / twist * rise / apix0 + 0.5)
+    assert ret[0].shape == (n0y, max(n0x, int(pitch_px * 1.2))) and ret[1].shape == ret[0].shape and ret[2].shape == (n0y, n0y)
