@@ -108,6 +108,8 @@ EXPORTS = {
     "hh_warp_affine_2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int,
                                     C.c_void_p]),
     "hh_rescale_2d": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hh_ssim_2d": (C.c_int, [C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_double, _f64p]),
+    "hh_joint_histogram": (C.c_int, [C.c_int, _f32p, _f32p, C.c_int64, _f64p, _f64p, C.c_int, C.POINTER(C.c_int64)]),
     "hh_helix_moments": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _f64p]),
     "hh_transform_map": (C.c_int, [C.c_int, _f32p, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, _f32p]),

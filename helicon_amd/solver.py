@@ -17,8 +17,11 @@ What runs where:
   reference with every matrix an ``hh_pa`` operator on the device and SciPy's own ``lsq_linear`` / ``lsqr`` driving them;
 * this module: argument handling, the positivity rule (:352-355), grouping, half sets, the volume assembly (:532-547).
 
-Not provided (``NotImplementedError``): model "ard", scores other than cosine.  There is no CPU fallback: without the
-library or a GPU the call raises.
+* the non-cosine scores of :484-524 ("ssim", "ms_ssim", "mutual_information", "composite"; ``helicon.ssim_score`` etc.,
+  lib/analysis.py:487-613 — scikit-image in the reference, pinned by derivation like the image preparation): ``ssim_score``,
+  ``ms_ssim_score``, ``mutual_information_score`` on the device (``hh_ssim_2d``, ``hh_joint_histogram``).
+
+Not provided (``NotImplementedError``): model "ard".  There is no CPU fallback: without the library or a GPU the call raises.
 """
 from __future__ import annotations
 
@@ -65,6 +68,126 @@ def cosine_similarity(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     norm = np.sqrt(_dot(a, a)) * np.sqrt(_dot(b, b))
     return 0 if norm == 0 else _dot(a, b) / norm
+
+
+def _f32_pair(img1, img2):
+    a, b = np.asarray(img1), np.asarray(img2)
+    if a.shape != b.shape:
+        raise ValueError(f"Image shapes must match: {a.shape} vs {b.shape}")   # lib/analysis.py:504-505
+    return np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+
+
+def _data_range(a, b):
+    return max(a.max() - a.min(), b.max() - b.min())
+
+
+def _ssim(a, b, data_range, device):
+    out = C.c_double()
+    _lib.check(_lib.lib().hh_ssim_2d(int(device), a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)),
+                                     a.shape[0], a.shape[1], float(data_range), C.byref(out)), None)
+    return float(out.value)
+
+
+def ssim_score(img1, img2, *, device=0):
+    """``helicon.ssim_score`` (lib/analysis.py:487-513): scikit-image's structural similarity with its defaults (7 x 7 uniform
+    window) at ``data_range`` = the larger of the two images' ranges, on the device (``hh_ssim_2d``); 0 for constant images
+    and for images the window does not fit (the reference swallows scikit-image's error and returns 0)."""
+    a, b = _f32_pair(img1, img2)
+    r = _data_range(a, b)
+    if r == 0 or a.ndim != 2 or min(a.shape) < 7:
+        return 0.0
+    return _ssim(a, b, r, device)
+
+
+def ms_ssim_score(img1, img2, *, device=0):
+    """``helicon.ms_ssim_score`` (lib/analysis.py:516-582): SSIM at up to five scales, each half the last (scikit-image's
+    ``rescale(img, 0.5, anti_aliasing=True)``: ``helicon_amd.rescale`` with linear interpolation), combined as a weighted
+    geometric mean."""
+    from .denovo3D import rescale
+
+    a, b = _f32_pair(img1, img2)
+    r = _data_range(a, b)
+    if r == 0 or a.ndim != 2:
+        return 0.0
+    weights = np.array([0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
+    vals = []
+    for i in range(len(weights)):
+        if a.shape[0] < 8 or a.shape[1] < 8:
+            break
+        vals.append(max(_ssim(a, b, r, device), 0.0))
+        if i < len(weights) - 1:
+            a, b = rescale(a, 0.5, order=1, device=device), rescale(b, 0.5, order=1, device=device)
+            r = _data_range(a, b)
+            if r == 0:
+                break
+    if not vals:
+        return 0.0
+    wts = weights[: len(vals)] / weights[: len(vals)].sum()
+    result = 1.0
+    for s_, w_ in zip(vals, wts):
+        result *= s_ ** w_
+    return float(result)
+
+
+def mutual_information_score(img1, img2, *, device=0):
+    """``helicon.mutual_information_score`` (lib/analysis.py:585-613): scikit-image's normalised mutual information with 64
+    bins, minus 1 — (H(a) + H(b)) / H(a, b) - 1 from the joint histogram, counted on the device (``hh_joint_histogram``; the
+    edges are ``np.histogramdd``'s: ``np.linspace(min, max, 65)`` per image)."""
+    a, b = _f32_pair(img1, img2)
+    bins = 64
+
+    def edges(v):
+        # np.histogramdd's own edges: np.linspace of the image's float32 extremes — float32 edges under NumPy 2's promotion
+        # rules — handed to the device as the float64 values they are
+        lo, hi = v.min(), v.max()
+        if lo == hi:   # np.histogramdd widens an empty range by one half either side
+            lo, hi = lo - 0.5, hi + 0.5
+        return np.linspace(lo, hi, bins + 1)
+
+    ea32, eb32 = edges(a), edges(b)
+    ea, eb = np.ascontiguousarray(ea32, dtype=np.float64), np.ascontiguousarray(eb32, dtype=np.float64)
+    counts = np.zeros((bins, bins), dtype=np.int64)
+    _lib.check(_lib.lib().hh_joint_histogram(int(device), a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)),
+                                             a.size, _p(ea), _p(eb), bins, counts.ctypes.data_as(C.POINTER(C.c_int64))), None)
+    # density=True, as scikit-image asks for it: counts over the bins' own widths (np.diff of those edges: not all equal in their
+    # last float32 digits) and over the total — the widths do not cancel exactly in the entropies
+    hist = counts.astype(np.float64)
+    total = hist.sum()
+    hist = hist / np.diff(ea32).reshape(bins, 1)
+    hist = hist / np.diff(eb32).reshape(1, bins)
+    hist = hist / total
+
+    def entropy(counts):   # scipy.stats.entropy: normalise, -sum p log p over p > 0
+        pk = counts.astype(np.float64).ravel()
+        pk = pk / pk.sum()
+        pk = pk[pk > 0]
+        return float(-(pk * np.log(pk)).sum())
+
+    h01 = entropy(hist)
+    if h01 == 0:   # (scikit-image divides by zero here and the reference returns what comes out: nan - 1)
+        return float("nan")
+    return (entropy(hist.sum(axis=0)) + entropy(hist.sum(axis=1))) / h01 - 1.0
+
+
+_SCORES_2D = ("ssim", "ms_ssim", "mutual_information", "composite")
+
+
+def _score_2d(metric, pred, b_data, pid, img, d2, l2, device):
+    """The 2-D scores of solver:484-524: the prediction scattered to its pixels of the (L2d, D2d) region against the
+    transposed input region."""
+    pred_2d = np.zeros((l2, d2), dtype=np.float32)
+    pred_2d.ravel()[pid] = pred
+    ny, nx = img.shape
+    ref_2d = np.ascontiguousarray(img[ny // 2 - d2 // 2: ny // 2 + d2 // 2, nx // 2 - l2 // 2: nx // 2 + l2 // 2].T, dtype=np.float32)
+    if metric == "ssim":
+        return ssim_score(pred_2d, ref_2d, device=device)
+    if metric == "ms_ssim":
+        return ms_ssim_score(pred_2d, ref_2d, device=device)
+    if metric == "mutual_information":
+        return mutual_information_score(pred_2d, ref_2d, device=device)
+    parts = [cosine_similarity(pred, b_data), ssim_score(pred_2d, ref_2d, device=device), ms_ssim_score(pred_2d, ref_2d, device=device),
+             mutual_information_score(pred_2d, ref_2d, device=device)]
+    return float(np.mean(parts))
 
 
 class PathAProblem:
@@ -500,7 +623,7 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                           thresh_fraction=-1, positive_constraint=-1, reconstruct_diameter_3d_inner_pixel=0,
                           reconstruct_diameter_2d_pixel=-1, reconstruct_diameter_3d_pixel=-1, reconstruct_length_2d_pixel=-1,
                           reconstruct_length_3d_pixel=-1, sym_oversample=1, fsc_test=0, *, interpolation="nn", return_3d=True,
-                          device=0, batch=128, streams=8, stats=None, algorithm=None):
+                          device=0, batch=128, streams=8, stats=None, algorithm=None, score_metric="cosine"):
     """``lsq_reconstruct`` (solver_linear_regression.py:31-547; nearest-neighbour projector, model "lsq", cosine score)
     for MANY (twist_degree, rise_pixel, csym) candidates of one image: the loop the reference's driver runs as a thread
     pool over ``process_one_task`` (app.py:2473-2476).  ``candidates`` is a sequence of ``(twist, rise, csym)``; the
@@ -532,7 +655,7 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
             maps, score = lsq_reconstruct(img, scale2d_to_3d, c[0], c[1], c[2], tilt_degree, psi_degree, dy_pixel, thresh_fraction,
                                           positive_constraint, reconstruct_diameter_3d_inner_pixel, reconstruct_diameter_2d_pixel,
                                           reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel, reconstruct_length_3d_pixel,
-                                          sym_oversample, interpolation, fsc_test, device=device, _single=True)
+                                          sym_oversample, interpolation, fsc_test, score_metric=score_metric, device=device, _single=True)
             return (maps if return_3d else (None, None, None)), score
 
         with ThreadPoolExecutor(max_workers=max(1, min(int(streams), len(cands)))) as pool:
@@ -575,25 +698,37 @@ def lsq_reconstruct_batch(projection_image, scale2d_to_3d, candidates, tilt_degr
                 raise ValueError("the cylinder does not fit the 2-D region's box (reconstruct_diameter_2d_pixel must hold "
                                  "the 3-D diameter): the reference's two masks would rank the voxels differently")
             clip = 1 if thresh_fraction >= 0 else 0
+            two_d = score_metric in _SCORES_2D
+            want_x = return_3d or two_d
             if model is None:
-                x, scores, info = B.solve(positive, clip, want_x=return_3d)
+                x, scores, info = B.solve(positive, clip, want_x=want_x)
             else:
                 alpha, rho, ridge_form = model
                 al = np.full(len(params), alpha, dtype=np.float64)
-                x, scores, info3, _ = B.solve_prox(positive, clip, al, rho, ridge_form, want_x=return_3d)
+                x, scores, info3, _ = B.solve_prox(positive, clip, al, rho, ridge_form, want_x=want_x)
                 # solver:331-338: an all-zero solution is refitted with alpha / 10 (elasticnet, lasso, ridge) until it is not
                 for _ in range(12):
                     zero = info3[:, 2] == 0
                     if not zero.any() or alpha == 0:
                         break
                     al = np.where(zero, al * 0.1, al)
-                    x2, s2, i2, _ = B.solve_prox(positive, clip, al, rho, ridge_form, want_x=return_3d)
+                    x2, s2, i2, _ = B.solve_prox(positive, clip, al, rho, ridge_form, want_x=want_x)
                     scores = np.where(zero, s2, scores)
                     info3 = np.where(zero[:, None], i2, info3)
-                    if return_3d:
+                    if want_x:
                         x = np.where(zero[:, None], x2, x)
                 info = np.concatenate([np.where(info3[:, 1:2] == 1, 1, 0), info3[:, :1], np.zeros_like(info3[:, :1]), info3[:, :1],
                                        np.zeros_like(info3[:, :1])], axis=1)   # status, iterations, -, iterations, -
+            if two_d:
+                # solver:484-524: the prediction A_data x (x as the float32 map), clipped with thresh_fraction >= 0, scattered to
+                # its pixels and scored against the input region
+                scores = np.array(scores, dtype=np.float64)
+                for c in range(len(params)):
+                    b_c, pid_c = B.rhs(c)
+                    pred = B.matvec(c, x[c].astype(np.float64))[: len(b_c)].astype(np.float32)
+                    if clip:
+                        pred = np.clip(pred, 0, None)
+                    scores[c] = _score_2d(score_metric, pred, b_c, pid_c, img, d2, l2, device)
             pids = [B.rhs(c)[1] for c in range(len(params))] if random_split else None
             counters = dict(B.counters(), device_bytes=B.device_bytes, info=info.tolist())
         return x, scores, counters, pids
@@ -771,8 +906,12 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
     if interpolation not in ("nn", "linear"):
         raise ValueError("interpolation must be 'nn' or 'linear'")
     model = _model_of(algorithm)
-    if score_metric not in ("cosine", "frc"):  # "frc" is documented but never dispatched: it falls through to cosine
-        raise NotImplementedError("scores other than cosine need scikit-image")
+    if score_metric not in ("cosine", "frc") + _SCORES_2D:  # "frc" is documented but never dispatched: it falls through to cosine
+        score_metric = "cosine"                              # (anything else falls through to cosine too, solver:523-524)
+    if score_metric in _SCORES_2D and fsc_test and fsc_test >= 1:
+        # solver:499-501 scatters a HALF set's prediction with the FULL set's pixel ids: NumPy refuses the assignment
+        raise ValueError("shape mismatch: a half set's prediction cannot be scattered with the full set's pixel ids "
+                         "(the reference fails the same way for 2-D scores with fsc_test >= 1)")
     refine = refine_tilt_psi_dy_range is not None and any(v > 0 for v in (refine_tilt_psi_dy_range.get(k, 0) for k in ("tilt", "psi", "dy")))
     img = np.asarray(projection_image)
     if _single and model is not None:
@@ -788,7 +927,7 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
                                      thresh_fraction, positive_constraint, reconstruct_diameter_3d_inner_pixel,
                                      reconstruct_diameter_2d_pixel, reconstruct_diameter_3d_pixel, reconstruct_length_2d_pixel,
                                      reconstruct_length_3d_pixel, sym_oversample, fsc_test, interpolation=interpolation, device=device,
-                                     algorithm=algorithm)[0]
+                                     algorithm=algorithm, score_metric=score_metric)[0]
     d3, l3 = int(reconstruct_diameter_3d_pixel), int(reconstruct_length_3d_pixel)
     d2 = int(reconstruct_diameter_2d_pixel) if reconstruct_diameter_2d_pixel > 0 else img.shape[0]
     l2 = int(reconstruct_length_2d_pixel) if reconstruct_length_2d_pixel > 0 else img.shape[1]
@@ -819,7 +958,10 @@ def lsq_reconstruct(projection_image, scale2d_to_3d, twist_degree, rise_pixel, c
             if thresh_fraction >= 0:
                 pred = np.clip(pred, 0, None)
             xs.append(x)
-            scores.append(cosine_similarity(pred, P.b_data.astype(np.float64)))
+            if score_metric in _SCORES_2D:
+                scores.append(_score_2d(score_metric, pred.astype(np.float32), P.b_data, P.b_pid, img, d2, l2, device))
+            else:
+                scores.append(cosine_similarity(pred, P.b_data.astype(np.float64)))
     score = scores[0] / 2 + (scores[1] + scores[2]) / 4 if len(scores) == 3 else scores[0]                # solver:526-529
     maps = []
     for x in xs:

@@ -275,6 +275,18 @@ int hh_rescale_2d(int device, const void* data, int is_f64, int rows, int cols, 
  * the rest is not meaningful. */
 int hh_helix_moments(int device, const void* data, int is_f64, int rows, int cols, double threshold, double out[8]);
 
+/* hh_ssim_2d — skimage.metrics.structural_similarity(a, b, data_range=...) with its defaults (7 x 7 uniform window, sample
+ * covariance, K1 = 0.01, K2 = 0.03) of two float32 images, what helicon.ssim_score and ms_ssim_score call (lib/analysis.py:
+ * 487-582; the "ssim" / "ms_ssim" / "composite" scores of lsq_reconstruct, solver:484-524): the mean of the SSIM map over the
+ * image without its 3-pixel rim, float32 arithmetic in numpy's operation order, the mean in float64.  rows, cols >= 7. */
+int hh_ssim_2d(int device, const float* a, const float* b, int rows, int cols, double data_range, double* out);
+
+/* hh_joint_histogram — the counts of np.histogramdd([a, b], bins) for skimage.metrics.normalized_mutual_information
+ * (helicon.mutual_information_score, lib/analysis.py:585-613): edges_a / edges_b are the caller's np.linspace(min, max,
+ * bins + 1); hist: int64 [bins][bins], first index = a's bin. */
+int hh_joint_histogram(int device, const float* a, const float* b, int64_t n, const double* edges_a, const double* edges_b, int bins,
+                       int64_t* hist);
+
 /* helicon.transform_map (lib/transforms.py:168-235; the reference's task function resamples the symmetrised map with
  * it when tilt / psi / dy are not zero, pipeline.py:430-432): data is host float32 [shape[0]][shape[1]][shape[2]] (z, y, x);
  * the sampling grid, centred on voxel (n // 2), is scaled, rotated by the intrinsic ZYZ Euler angles (rot, tilt, psi;

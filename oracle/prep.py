@@ -250,3 +250,88 @@ def auto_horizontalize(data, refine=False):
 
         theta, shift_y = fmin(score, x0=(theta, shift_y), xtol=1e-2, disp=0)
     return rotate_shift_image(data, angle=theta, post_shift=(shift_y, 0), order=3), theta, shift_y
+
+
+# ------------------------------------------------------------------------------------------- non-cosine scores (skimage.metrics)
+def structural_similarity(im1, im2, data_range):
+    """skimage.metrics.structural_similarity(im1, im2, data_range=...) with its defaults (metrics/_structural_similarity.py,
+    scikit-image 0.25: 7 x 7 uniform window, sample covariance, K1 0.01, K2 0.03), in numpy's own float32 arithmetic, the
+    uniform filters MADE with scipy.ndimage.uniform_filter as scikit-image makes them."""
+    if min(im1.shape) < 7:
+        raise ValueError("win_size exceeds image extent")
+    float_type = np.float32 if im1.dtype in (np.float16, np.float32) else np.float64
+    im1 = im1.astype(float_type, copy=False)
+    im2 = im2.astype(float_type, copy=False)
+    NP = 49
+    cov_norm = NP / (NP - 1)
+    ux, uy = ndi.uniform_filter(im1, size=7), ndi.uniform_filter(im2, size=7)
+    uxx, uyy, uxy = ndi.uniform_filter(im1 * im1, size=7), ndi.uniform_filter(im2 * im2, size=7), ndi.uniform_filter(im1 * im2, size=7)
+    vx = cov_norm * (uxx - ux * ux)
+    vy = cov_norm * (uyy - uy * uy)
+    vxy = cov_norm * (uxy - ux * uy)
+    R = data_range
+    C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+    A1, A2, B1, B2 = 2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2
+    S = (A1 * A2) / (B1 * B2)
+    return S[3:-3, 3:-3].mean(dtype=np.float64)
+
+
+def ssim_score(img1, img2):
+    """helicon.ssim_score (lib/analysis.py:487-513)."""
+    if img1.shape != img2.shape:
+        raise ValueError(f"Image shapes must match: {img1.shape} vs {img2.shape}")
+    try:
+        data_range = max(img1.max() - img1.min(), img2.max() - img2.min())
+        if data_range == 0:
+            return 0.0
+        return float(structural_similarity(img1, img2, data_range=data_range))
+    except Exception:
+        return 0.0
+
+
+def ms_ssim_score(img1, img2):
+    """helicon.ms_ssim_score (lib/analysis.py:516-582): SSIM at up to five scales, each half the last (``rescale(img, 0.5,
+    anti_aliasing=True)``: linear interpolation for a floating image), combined as a weighted geometric mean."""
+    if img1.shape != img2.shape:
+        raise ValueError(f"Image shapes must match: {img1.shape} vs {img2.shape}")
+    try:
+        data_range = max(img1.max() - img1.min(), img2.max() - img2.min())
+        if data_range == 0:
+            return 0.0
+        all_weights = np.array([0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
+        vals = []
+        for i in range(len(all_weights)):
+            h, w = img1.shape
+            if h < 8 or w < 8:
+                break
+            vals.append(max(structural_similarity(img1, img2, data_range=data_range), 0.0))
+            if i < len(all_weights) - 1:
+                img1, img2 = rescale(img1, 0.5, order=1), rescale(img2, 0.5, order=1)
+                data_range = max(img1.max() - img1.min(), img2.max() - img2.min())
+                if data_range == 0:
+                    break
+        if not vals:
+            return 0.0
+        wts = all_weights[: len(vals)]
+        wts = wts / wts.sum()
+        result = 1.0
+        for s_, w_ in zip(vals, wts):
+            result *= s_ ** w_
+        return float(result)
+    except Exception:
+        return 0.0
+
+
+def mutual_information_score(img1, img2):
+    """helicon.mutual_information_score (lib/analysis.py:585-613): skimage.metrics.normalized_mutual_information(bins=64) - 1;
+    scikit-image forms it from np.histogramdd and scipy.stats.entropy."""
+    from scipy.stats import entropy
+
+    if img1.shape != img2.shape:
+        raise ValueError(f"Image shapes must match: {img1.shape} vs {img2.shape}")
+    try:
+        hist, _ = np.histogramdd([np.reshape(img1, -1), np.reshape(img2, -1)], bins=64, density=True)
+        H0, H1, H01 = entropy(np.sum(hist, axis=0)), entropy(np.sum(hist, axis=1)), entropy(np.reshape(hist, -1))
+        return float((H0 + H1) / H01 - 1.0)
+    except Exception:
+        return 0.0

@@ -106,3 +106,25 @@ def test_closing_and_helix_estimates():
         rot3, _, _ = P.estimate_helix_rotation_center_diameter(out)
         assert angle == 0.0 or abs(rot3) > 1.5 * abs(rot)      # (the box clips a bar at 50 degrees)
     assert P.estimate_helix_rotation_center_diameter(np.zeros((16, 16), np.float32)) == (0.0, 0.0, 16)
+
+
+def test_non_cosine_scores_of_the_oracle():
+    """The restated scikit-image metrics (pinned by derivation): identities and orderings they must satisfy."""
+    rng = np.random.default_rng(5)
+    a = ndi.gaussian_filter(rng.random((64, 128)), 2.0).astype(np.float32)
+    b = (a + 0.02 * rng.standard_normal(a.shape)).astype(np.float32)
+    c = (a + 0.2 * rng.standard_normal(a.shape)).astype(np.float32)
+    assert P.ssim_score(a, a) == pytest.approx(1.0, abs=1e-6) and P.ms_ssim_score(a, a) == pytest.approx(1.0, abs=1e-6)
+    assert 1.0 > P.ssim_score(a, b) > P.ssim_score(a, c) > 0
+    assert 1.0 > P.ms_ssim_score(a, b) > P.ms_ssim_score(a, c) > 0
+    assert P.mutual_information_score(a, a) == pytest.approx(1.0, abs=1e-9)          # H(a) + H(a) over H(a, a) = 2
+    assert P.mutual_information_score(a, b) > P.mutual_information_score(a, c) > 0
+    assert P.mutual_information_score(a, b) == pytest.approx(P.mutual_information_score(b, a), abs=1e-12)
+    assert P.ssim_score(np.ones((16, 16), np.float32), np.ones((16, 16), np.float32)) == 0.0      # no range
+    assert P.ssim_score(a[:5], b[:5]) == 0.0                                                     # the window does not fit: swallowed
+    with pytest.raises(ValueError):
+        P.ssim_score(a, b[:, :10])
+    # the SSIM of the interior does not depend on how the filter treats the rim
+    want = P.structural_similarity(a, b, data_range=float(max(np.ptp(a), np.ptp(b))))
+    ux = ndi.uniform_filter(a.astype(np.float64), 7, mode="constant")
+    assert np.isfinite(want) and ux.shape == a.shape
