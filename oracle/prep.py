@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY.  Nothing under ``helicon_amd/`` may import this module; it is imported by ``tests/`` only,
 as the checker of ``helicon_amd.transform_image`` / ``rescale`` / ``down_scale`` /
-``estimate_helix_rotation_center_diameter`` / ``auto_horizontalize``.
+``estimate_helix_rotation_center_diameter`` / ``auto_horizontalize`` and of ``helicon_amd.solver``'s non-cosine scores.
 
 PARITY PINNED BY DERIVATION.  scikit-image is a dependency of the reference (pyproject.toml:17, unpinned) that is NOT
 installed in the build container, so the reference's own functions for this row cannot be run here and no reference
@@ -31,6 +31,11 @@ output exists to pin against.  What this module restates, and from where:
   reference itself)
 * ``auto_horizontalize``    reference: src/helicon/webApps/denovo3D/utils.py:383-424
 * ``set_to_periodic_range`` reference: src/helicon/lib/angular.py:84-108
+* ``ssim_score`` / ``ms_ssim_score`` / ``mutual_information_score``  reference: src/helicon/lib/analysis.py:487-613 (the
+  non-cosine scores of ``lsq_reconstruct``, solver_linear_regression.py:484-524): ``skimage.metrics.structural_similarity``
+  (metrics/_structural_similarity.py, scikit-image 0.25, defaults) restated with ``scipy.ndimage.uniform_filter`` as
+  scikit-image calls it, ``skimage.metrics.normalized_mutual_information`` with ``np.histogramdd`` and
+  ``scipy.stats.entropy`` as scikit-image calls them
 """
 from __future__ import annotations
 
