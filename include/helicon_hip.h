@@ -17,6 +17,8 @@
  *   hh_warp_affine_2d      lib/transforms.py:238-312          transform_image (its skimage.transform.warp call)
  *   hh_rescale_2d          lib/filters.py:375-412             down_scale, and the app's binning (their skimage rescale call)
  *   hh_helix_moments       lib/analysis.py:645-728            estimate_helix_rotation_center_diameter (closing + moments)
+ *   hh_ssim_2d,            lib/analysis.py:487-613            ssim_score / ms_ssim_score / mutual_information_score: the non-cosine
+ *   hh_joint_histogram                                        scores of lsq_reconstruct (solver_linear_regression.py:484-524)
  *   hh_set_reference +     webApps/denovo3D/app.py:2455-2523  reconstruction_task (the pool over
  *   hh_sweep[_device]                                         candidates) scoring each candidate by
  *                                                             cc(ref[mask], pwr[mask])
